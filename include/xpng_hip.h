@@ -1,0 +1,86 @@
+/* xpng_hip.h -- C-ABI of libxpng_hip.so: the MI355X tile codec behind xpng_store / xpng_load.
+ *
+ * This is the "inner boundary" of SURVEY.md §8(b): it replaces the two pthread fan-outs of the
+ * reference driver,
+ *     spawn_and_wait(T, &d, 0, enc_1_th | enc_2_th)   reference libxpng.c:758
+ *     spawn_and_wait(T, &d, 0, dec_1_th | dec_2_th)   reference libxpng.c:983
+ * i.e. "given the raster and the tile table, produce every tile's blob" and the reverse.  Plain
+ * pointers and sizes only; no C++ or torch types.  All functions return 0 on success, non-zero on
+ * failure (the reference's _Bool convention, libxpng.c:729-731); xpnghip_last_error() describes the
+ * last failure of the calling thread.  There is NO CPU fallback: without a usable HIP device every
+ * compute entry point fails.
+ */
+#ifndef XPNG_HIP_H
+#define XPNG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XPNGHIP_ABI_VERSION 1
+
+int xpnghip_abi_version(void);
+int xpnghip_device_count(void);          /* visible HIP devices; 0 when none / no runtime */
+const char *xpnghip_last_error(void);
+
+/* ---- host-buffer entry points: what the host C driver (xpng_store_T / xpng_load_T) calls ----------
+ *
+ * xpnghip_encode_tiles  <->  libxpng.c:758 + the concatenation loop libxpng.c:764-769.
+ *   raster: normalised interleaved raster, w*h*pxsz bytes (pxsz 3 or 4), host memory.
+ *   mode:   1 (enc_1_th, RGB and RGBA) or 2 (enc_2_th, RGB only).
+ *   *blobs: malloc()ed concatenation of all tile blobs in tile order (caller frees with free()).
+ * xpnghip_decode_tiles  <->  libxpng.c:982-983.
+ *   blobs:  the file body after the 8-byte header; tile sizes are walked serially as the reference does.
+ *   raster: caller-allocated w*h*pxsz bytes, filled completely.
+ */
+int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz,
+                         uint8_t **blobs, uint64_t *blobs_len);
+int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
+                         int pxsz, uint8_t *raster);
+
+/* ---- device-resident entry points (bench, multi-GPU sharding, pipelines) ---------------------------
+ *
+ * A context owns the tile table (libxpng.c:51-83) and every intermediate buffer for one raster
+ * geometry on one device, so the hot path itself performs no allocation and no host sync except the
+ * final 8-byte length read-back.  `stream` is a hipStream_t passed as void* (NULL = the context's own).
+ */
+typedef struct xpnghip_ctx xpnghip_ctx;
+
+int xpnghip_ctx_create(xpnghip_ctx **ctx, int device, uint64_t w, uint64_t h, int pxsz);
+void xpnghip_ctx_destroy(xpnghip_ctx *ctx);
+uint64_t xpnghip_ctx_tile_count(const xpnghip_ctx *ctx);
+/* tile i -> {x, y, w, h} (pixels); returns non-zero if i is out of range */
+int xpnghip_ctx_tile(const xpnghip_ctx *ctx, uint64_t i, uint64_t xywh[4]);
+/* upper bound of the concatenated blobs of tiles [t0, t1) (raw fallback bound: sum(w*h*pxsz + 4)) */
+uint64_t xpnghip_ctx_blob_bound(const xpnghip_ctx *ctx, uint64_t t0, uint64_t t1);
+uint64_t xpnghip_ctx_workspace_bytes(const xpnghip_ctx *ctx);
+
+/* Encode tiles [t0, t1) of the device raster `d_raster` (full w*h*pxsz image, device pointer) into
+ * `d_blobs` (device pointer, capacity >= xpnghip_ctx_blob_bound).  On return *blobs_len is the byte
+ * count (one stream sync).  Pass blobs_len == NULL to skip the sync and read the length later with
+ * xpnghip_ctx_last_blobs_len() after synchronising the stream yourself. */
+int xpnghip_encode_device(xpnghip_ctx *ctx, int mode, const void *d_raster, uint64_t t0, uint64_t t1,
+                          void *d_blobs, uint64_t *blobs_len, void *stream);
+uint64_t xpnghip_ctx_last_blobs_len(xpnghip_ctx *ctx);
+
+/* Decode tiles [t0, t1).  d_blobs holds their concatenated blobs (device); tile_off[i - t0] is the byte
+ * offset of tile i's blob inside d_blobs (host array from the serial size walk, libxpng.c:982). */
+int xpnghip_decode_device(xpnghip_ctx *ctx, int mode, const void *d_blobs, uint64_t blobs_len,
+                          const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream);
+
+/* Stage-only run for BASELINE config 2: predictor chooser + per-pixel transform (libxpng.c:92-140 and
+ * the arithmetic of 497-519) over tiles [t0, t1); symbol planes stay in the context's workspace. */
+int xpnghip_m1_transform_device(xpnghip_ctx *ctx, const void *d_raster, uint64_t t0, uint64_t t1, void *stream);
+
+/* ---- introspection for parity tests (copies intermediates of the LAST encode to host) --------------
+ * what: 0 = predictor byte pr (1 B), 1..5 = planes nl,r,g,b,a (w*h B each, tile-linear),
+ *       10..18 = context stream 0..8, 19 = residual bit-stream words k, 20..29 = rANS block 0..9,
+ *       30 = chooser cost sums (16 B).  Returns bytes written to `out` (<= cap) or -1. */
+int64_t xpnghip_debug_fetch(xpnghip_ctx *ctx, int what, uint64_t tile, void *out, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,231 @@
+"""ctypes binding of libxpng_hip.so (include/xpng_hip.h) and libxpng.so (include/xpng.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "xpng_amd", "lib")
+HIP_SO = os.path.join(LIBDIR, "libxpng_hip.so")
+HOST_SO = os.path.join(LIBDIR, "libxpng.so")
+CLI = os.path.join(ROOT, "xpng_amd", "bin", "xpng")
+
+# every symbol include/xpng_hip.h declares (tests/test_abi.py checks the .so exports all of them)
+HIP_SYMBOLS = [
+    "xpnghip_abi_version", "xpnghip_device_count", "xpnghip_last_error", "xpnghip_encode_tiles",
+    "xpnghip_decode_tiles", "xpnghip_ctx_create", "xpnghip_ctx_destroy", "xpnghip_ctx_tile_count",
+    "xpnghip_ctx_tile", "xpnghip_ctx_blob_bound", "xpnghip_ctx_workspace_bytes", "xpnghip_encode_device",
+    "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
+]
+HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
+                "store_7", "load_7"]
+
+
+class XpngError(RuntimeError):
+    pass
+
+
+def native_paths():
+    return {"hip": HIP_SO, "host": HOST_SO, "cli": CLI}
+
+
+def build_native(targets=("hip", "host")) -> None:
+    """Compile the native libraries in-tree (hipcc --offload-arch=gfx950; works without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", ROOT, *targets])
+
+
+class XpngT(C.Structure):  # include/xpng.h xpng_t
+    _fields_ = [("p", C.POINTER(C.c_uint8)), ("w", C.c_uint64), ("h", C.c_uint64), ("s", C.c_uint64), ("A", C.c_bool)]
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise XpngError(f"{HIP_SO} is missing: run `make hip` (there is no CPU fallback)")
+        L = C.CDLL(HIP_SO)
+        u64, vp = C.c_uint64, C.c_void_p
+        L.xpnghip_abi_version.restype = C.c_int
+        L.xpnghip_device_count.restype = C.c_int
+        L.xpnghip_last_error.restype = C.c_char_p
+        L.xpnghip_encode_tiles.restype = C.c_int
+        L.xpnghip_encode_tiles.argtypes = [C.c_int, vp, u64, u64, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
+        L.xpnghip_decode_tiles.restype = C.c_int
+        L.xpnghip_decode_tiles.argtypes = [C.c_int, vp, u64, u64, u64, C.c_int, vp]
+        L.xpnghip_ctx_create.restype = C.c_int
+        L.xpnghip_ctx_create.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int]
+        L.xpnghip_ctx_destroy.restype = None
+        L.xpnghip_ctx_destroy.argtypes = [vp]
+        L.xpnghip_ctx_tile_count.restype = u64
+        L.xpnghip_ctx_tile_count.argtypes = [vp]
+        L.xpnghip_ctx_tile.restype = C.c_int
+        L.xpnghip_ctx_tile.argtypes = [vp, u64, C.POINTER(u64)]
+        L.xpnghip_ctx_blob_bound.restype = u64
+        L.xpnghip_ctx_blob_bound.argtypes = [vp, u64, u64]
+        L.xpnghip_ctx_workspace_bytes.restype = u64
+        L.xpnghip_ctx_workspace_bytes.argtypes = [vp]
+        L.xpnghip_encode_device.restype = C.c_int
+        L.xpnghip_encode_device.argtypes = [vp, C.c_int, vp, u64, u64, vp, C.POINTER(u64), vp]
+        L.xpnghip_ctx_last_blobs_len.restype = u64
+        L.xpnghip_ctx_last_blobs_len.argtypes = [vp]
+        L.xpnghip_decode_device.restype = C.c_int
+        L.xpnghip_decode_device.argtypes = [vp, C.c_int, vp, u64, C.POINTER(u64), u64, u64, vp, vp]
+        L.xpnghip_m1_transform_device.restype = C.c_int
+        L.xpnghip_m1_transform_device.argtypes = [vp, vp, u64, u64, vp]
+        L.xpnghip_debug_fetch.restype = C.c_int64
+        L.xpnghip_debug_fetch.argtypes = [vp, C.c_int, u64, vp, u64]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_SO):
+            raise XpngError(f"{HOST_SO} is missing: run `make host`")
+        hip_lib()
+        L = C.CDLL(HOST_SO)
+        for name in ("xpng_store", "xpng_load", "store_7", "load_7"):
+            getattr(L, name).restype = C.c_bool
+        L.xpng_store.argtypes = [C.c_uint64, C.POINTER(XpngT), C.c_char_p]
+        L.xpng_load.argtypes = [C.c_char_p, C.POINTER(XpngT)]
+        L.store_7.argtypes = [C.POINTER(XpngT), C.c_char_p]
+        L.load_7.argtypes = [C.c_char_p, C.POINTER(XpngT)]
+        _host = L
+    return _host
+
+
+def _err():
+    return hip_lib().xpnghip_last_error().decode(errors="replace")
+
+
+def device_count() -> int:
+    return hip_lib().xpnghip_device_count()
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def encode_tiles(mode: int, raster: np.ndarray) -> bytes:
+    """Host raster (h, w, 3|4) uint8 -> concatenated tile blobs (xpnghip_encode_tiles; H2D + kernels + D2H)."""
+    raster = np.ascontiguousarray(raster, dtype=np.uint8)
+    h, w, ch = raster.shape
+    p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+    if hip_lib().xpnghip_encode_tiles(mode, raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(p), C.byref(n)):
+        raise XpngError("xpnghip_encode_tiles: " + _err())
+    out = C.string_at(p, n.value)
+    _libc.free(p)
+    return out
+
+
+def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int) -> np.ndarray:
+    raster = np.zeros((h, w, pxsz), dtype=np.uint8)
+    buf = np.frombuffer(blobs, dtype=np.uint8)
+    if hip_lib().xpnghip_decode_tiles(mode, buf.ctypes.data_as(C.c_void_p), len(blobs), w, h, pxsz,
+                                      raster.ctypes.data_as(C.c_void_p)):
+        raise XpngError("xpnghip_decode_tiles: " + _err())
+    return raster
+
+
+def store(mode: int, raster: np.ndarray, path: str) -> None:
+    """xpng_store (include/xpng.h): full host driver incl. normalisation, fallbacks and file output."""
+    raster = np.ascontiguousarray(raster, dtype=np.uint8)
+    h, w, ch = raster.shape
+    pm = XpngT(raster.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, raster.size, ch == 4)
+    if host_lib().xpng_store(mode, C.byref(pm), path.encode()):
+        raise XpngError("xpng_store failed")
+
+
+def load(path: str) -> np.ndarray:
+    pm = XpngT()
+    if host_lib().xpng_load(path.encode(), C.byref(pm)):
+        raise XpngError("xpng_load failed")
+    out = np.ctypeslib.as_array(pm.p, shape=(pm.h, pm.w, 3 + int(pm.A))).copy()
+    _libc.free(pm.p)
+    return out
+
+
+class Context:
+    """xpnghip_ctx: tile table + device workspace for one raster geometry on one GPU.  Device pointers are
+    plain integers (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t handle or 0."""
+
+    FETCH = {"pr": 0, "nl": 1, "r": 2, "g": 3, "b": 4, "a": 5, "k": 19, "sums": 30}
+
+    def __init__(self, w: int, h: int, pxsz: int, device: int = 0):
+        self.w, self.h, self.pxsz, self.device = w, h, pxsz, device
+        self._h = C.c_void_p()
+        if hip_lib().xpnghip_ctx_create(C.byref(self._h), device, w, h, pxsz):
+            raise XpngError("xpnghip_ctx_create: " + _err())
+        self.n_tiles = hip_lib().xpnghip_ctx_tile_count(self._h)
+
+    def close(self):
+        if self._h:
+            hip_lib().xpnghip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tile(self, i: int):
+        a = (C.c_uint64 * 4)()
+        if hip_lib().xpnghip_ctx_tile(self._h, i, a):
+            raise IndexError(i)
+        return tuple(a)
+
+    def tiles(self):
+        return [self.tile(i) for i in range(self.n_tiles)]
+
+    def blob_bound(self, t0=0, t1=None) -> int:
+        return hip_lib().xpnghip_ctx_blob_bound(self._h, t0, self.n_tiles if t1 is None else t1)
+
+    def workspace_bytes(self) -> int:
+        return hip_lib().xpnghip_ctx_workspace_bytes(self._h)
+
+    def encode_device(self, mode, d_raster: int, d_blobs: int, t0=0, t1=None, stream=0, sync=True) -> int:
+        n = C.c_uint64()
+        rc = hip_lib().xpnghip_encode_device(self._h, mode, d_raster, t0, self.n_tiles if t1 is None else t1, d_blobs,
+                                             C.byref(n) if sync else None, stream)
+        if rc:
+            raise XpngError("xpnghip_encode_device: " + _err())
+        return n.value
+
+    def last_blobs_len(self) -> int:
+        return hip_lib().xpnghip_ctx_last_blobs_len(self._h)
+
+    def decode_device(self, mode, d_blobs: int, blobs_len: int, tile_off, d_raster: int, t0=0, t1=None, stream=0):
+        t1 = self.n_tiles if t1 is None else t1
+        arr = (C.c_uint64 * (t1 - t0))(*tile_off)
+        if hip_lib().xpnghip_decode_device(self._h, mode, d_blobs, blobs_len, arr, t0, t1, d_raster, stream):
+            raise XpngError("xpnghip_decode_device: " + _err())
+
+    def transform_device(self, d_raster: int, t0=0, t1=None, stream=0):
+        if hip_lib().xpnghip_m1_transform_device(self._h, d_raster, t0, self.n_tiles if t1 is None else t1, stream):
+            raise XpngError("xpnghip_m1_transform_device: " + _err())
+
+    def fetch(self, what, tile: int, cap: int = 1 << 22) -> np.ndarray:
+        code = self.FETCH[what] if isinstance(what, str) else what
+        buf = np.zeros(cap, dtype=np.uint8)
+        n = hip_lib().xpnghip_debug_fetch(self._h, code, tile, buf.ctypes.data_as(C.c_void_p), cap)
+        if n < 0:
+            raise XpngError(f"debug_fetch({what}, {tile}) failed")
+        return buf[:n].copy()
+
+
+def walk_tile_offsets(blobs: bytes, n_tiles: int):
+    """Serial size walk of the reference decoder (libxpng.c:982): blob start offsets of every tile."""
+    off, o = [], 0
+    for _ in range(n_tiles):
+        off.append(o)
+        o += int.from_bytes(blobs[o:o + 4], "little") & 0xFFFFFF
+    return off, o

@@ -1,0 +1,83 @@
+// common.hpp -- shared device/host definitions of the MI355X xPNG tile codec (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xpng {
+
+constexpr uint32_t TILE_AREA = 444u * 444u;  // reference libxpng.c:49
+constexpr uint32_t NL_NONE = 0xFFu;          // nl-plane marker: pixel emits no colour symbol
+constexpr int WAVE = 64;
+
+// One tile of the image (reference task_t, libxpng.c:46) plus where its intermediates live.
+struct TileDesc {
+    uint32_t x, y, w, h;  // top-left pixel and size inside the raster
+    uint32_t n;           // w*h
+    uint32_t _pad;
+    uint64_t pbase;       // first index of this tile in each symbol plane (multiple of 256)
+    uint64_t sbase;       // byte offset of this tile's stream scratch (multiple of 256)
+};
+
+// Stream-scratch layout of one tile, all offsets relative to TileDesc::sbase and derived from n only,
+// so that host and device agree without a table.  Capacities are worst cases:
+//   context stream  : <= n-1 symbols, 1 B each
+//   k bit stream    : 8*pxsz bits + <= 24 bits/pixel
+//   rANS v2 block   : 12 B header + ceil(n*pb/32) words + 16 B states + table (<= 256*16 bits)
+__host__ __device__ inline uint64_t rup(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ inline uint64_t ctx_cap(uint32_t n) { return rup((uint64_t)n + 16, 256); }
+__host__ __device__ inline uint64_t kw_cap(uint32_t n) { return rup(3ull * n + 64, 256); }
+__host__ __device__ inline uint64_t ctxblk_cap(uint32_t n) { return rup(3ull * n / 2 + 128, 256); }
+__host__ __device__ inline uint64_t alphablk_cap(uint32_t n) { return rup(2ull * n + 1280, 256); }
+__host__ __device__ inline uint64_t off_ctx(uint32_t n, int c) { return (uint64_t)c * ctx_cap(n); }
+__host__ __device__ inline uint64_t off_kw(uint32_t n) { return 9 * ctx_cap(n); }
+__host__ __device__ inline uint64_t off_blk(uint32_t n, int c) {  // c = 0..8 context blocks, 9 = alpha
+    return off_kw(n) + kw_cap(n) + (uint64_t)c * ctxblk_cap(n);
+}
+__host__ __device__ inline uint64_t tile_scratch_bytes(uint32_t n) { return off_blk(n, 9) + alphablk_cap(n); }
+
+// ---- integer helpers shared by encode and decode (reference libxpng.c:19-30) ----------------------
+__device__ __forceinline__ int bit_width(uint32_t v) { return v ? 32 - __clz((int)v) : 0; }  // numBit
+__device__ __forceinline__ int zz_enc(int d) {                                                 // pix_toU
+    int v = (int)(int8_t)d;
+    return ((v << 1) ^ (v >> 31)) & 0xFF;
+}
+__device__ __forceinline__ int zz_dec(int u) { return (u >> 1) ^ -(u & 1); }                   // pix_toS
+__device__ __forceinline__ int pred_avg(int L, int U) { return (L + U + 1) >> 1; }            // p2a
+__device__ __forceinline__ int pred_grad(int L, int U, int UL) { return ((3 * L + 3 * U - 2 * UL) + 2) >> 2; }  // p3a
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    uint32_t lane = threadIdx.x & 63u;
+    return lane ? (~0ull >> (64 - lane)) : 0ull;
+}
+
+// predictor flags from the four sampled cost sums: first minimum wins (libxpng.c:133-139);
+// tiles narrower than 4 px get 0 (libxpng.c:94)
+__device__ __forceinline__ int pr_from_sums(const uint32_t *s, int pxsz, uint32_t tw, uint32_t th) {
+    if (tw < 4 || th < 4) return 0;
+    int m = 0;
+    uint32_t r = s[0];
+    if (s[1] < r) { m = 1; r = s[1]; }
+    if (s[2] < r) { m = 2; r = s[2]; }
+    if (s[3] < r) { m = 3; r = s[3]; }
+    return (pxsz & 4) | m;
+}
+
+// packed pixel load: r | g<<8 | b<<16 (| a<<24).  Rasters are 4-byte aligned, so is every RGBA pixel.
+template <int PXSZ>
+__device__ __forceinline__ uint32_t load_px(const uint8_t *p) {
+    if constexpr (PXSZ == 4) {
+        return *reinterpret_cast<const uint32_t *>(p);
+    } else {
+        return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+}
+
+constexpr uint64_t RANS_L = 1ull << 31;  // reference RANS64_L, libxpng.c:153
+
+// swap values between lanes 2k and 2k+1 (DPP quad_perm [1,0,3,2]); VALU only, no LDS round trip
+__device__ __forceinline__ uint32_t swap_pair(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+
+}  // namespace xpng

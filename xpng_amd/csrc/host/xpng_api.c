@@ -1,0 +1,176 @@
+/* xpng_api.c -- host driver of the MI355X xPNG library: the drop-in for the reference's
+ * xpng_store_T / xpng_load_T (libxpng.c:723-789, 963-997).
+ *
+ * Everything the reference driver does around its two thread fan-outs stays here, in C, with the same
+ * observable behaviour: validation, normalize_RGBA, the `s <= 4 -> level 7` rule, the whole-image
+ * single-colour shortcut of level 2, the RGBA level-2 -> level-1 fallback, the file header, the
+ * "compressed >= raw -> rewrite as level 7" rule, and the stdout MPx/s line.  The fan-outs themselves
+ * (libxpng.c:758, 983) are replaced by xpnghip_encode_tiles / xpnghip_decode_tiles (include/xpng_hip.h),
+ * which run on the GPU.  There is no CPU codec in this library: if no HIP device is usable the call
+ * fails (returns 1), except for the paths that never reach the tile codec (level 7, single colour).
+ */
+#include "../../../include/xpng.h"
+#include "../../../include/xpng_hip.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define XPNG_MAX_DIM (1u << 24)
+
+static uint64_t now_ns(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+static void put_u32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+static uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+/* libxpng.c:688-721.  Returns 1 on allocation failure.  *out stays NULL when the raster is kept. */
+static int normalize_rgba(const xpng_t *in, uint8_t **out, uint64_t *s, _Bool *A) {
+    *out = NULL; *s = in->s; *A = in->A;
+    if (!in->A) return 0;
+    const uint64_t n = in->w * in->h;
+    const uint8_t *p = in->p;
+    int hidden = 0, translucent = 0;
+    for (uint64_t i = 0; i < n; i++, p += 4) {
+        if (p[3] == 0 && (p[0] | p[1] | p[2])) { hidden = 1; break; }
+        if (p[3] != 255) translucent = 1;
+    }
+    if (hidden) {
+        uint8_t *q = malloc(in->s);
+        if (!q) return 1;
+        p = in->p;
+        for (uint64_t i = 0; i < n; i++, p += 4) {
+            if (p[3]) memcpy(q + 4 * i, p, 4); else memset(q + 4 * i, 0, 4);
+        }
+        *out = q;
+        return 0;
+    }
+    if (translucent) return 0;
+    uint8_t *q = malloc(n * 3);
+    if (!q) return 1;
+    p = in->p;
+    for (uint64_t i = 0; i < n; i++, p += 4) { q[3 * i] = p[0]; q[3 * i + 1] = p[1]; q[3 * i + 2] = p[2]; }
+    *out = q; *s = n * 3; *A = 0;
+    return 0;
+}
+
+static int all_pixels_equal(const uint8_t *p, uint64_t n, int pxsz) { /* whole-image form of libxpng.c:628-643 */
+    for (uint64_t i = 1; i < n; i++) if (memcmp(p, p + i * (uint64_t)pxsz, (size_t)pxsz)) return 0;
+    return 1;
+}
+
+static _Bool write_file(const char *fn, const uint8_t hdr[8], const uint8_t *body, uint64_t len) {
+    FILE *f = fopen(fn, "wb");
+    if (!f) return 1;
+    _Bool bad = fwrite(hdr, 1, 8, f) != 8 || (len && fwrite(body, 1, len, f) != len);
+    return (_Bool)(fclose(f) != 0) || bad;
+}
+
+static void print_rate(const char *what, uint64_t workers, uint64_t ns, uint64_t pixels) {
+    if (!ns) ns = 1; /* same line shape as libxpng.c:761-762 / 986-987 */
+    printf("%s, %3d thread%c: %5lu MPx/s\n", what, (int)workers, workers > 1 ? 's' : ' ',
+           (unsigned long)((1e9 / (double)ns) * ((double)pixels / 1e6)));
+}
+
+_Bool xpng_store_T(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn) {
+    const uint64_t t_start = now_ns();
+    (void)T; /* one GPU per process; multi-GPU sharding is driven through xpnghip_encode_device */
+    if (!pm || !fn || !pm->p || !pm->w || !pm->h || pm->w > XPNG_MAX_DIM || pm->h > XPNG_MAX_DIM ||
+        !(mode == 1 || mode == 2 || mode == 7) || pm->w * pm->h * (3u + pm->A) != pm->s)
+        return 1; /* libxpng.c:729-731 */
+    uint8_t *owned = NULL;
+    uint64_t s;
+    _Bool A;
+    if (normalize_rgba(pm, &owned, &s, &A)) return 1;
+    const uint8_t *raster = owned ? owned : pm->p;
+    const int pxsz = 3 + A;
+    _Bool rc = 1;
+    uint8_t hdr[8];
+    if (s <= 4) mode = 7; /* libxpng.c:735 */
+    put_u32(hdr, (uint32_t)(pm->w - 1) | ((uint32_t)mode << 24));
+    put_u32(hdr + 4, (uint32_t)(pm->h - 1) | ((uint32_t)A << 24));
+    if (mode == 7) { rc = write_file(fn, hdr, raster, s); goto done; }
+    if (mode == 2 && all_pixels_equal(raster, pm->w * pm->h, pxsz)) { /* libxpng.c:741-753 */
+        hdr[7] |= 2;
+        rc = write_file(fn, hdr, raster, (uint64_t)pxsz);
+        goto done;
+    }
+    if (A && mode == 2) { mode = 1; hdr[3] = 1; } /* libxpng.c:755 */
+    if (A && (pm->w < 4 || pm->h < 4)) { /* reference behaviour undefined here: store uncompressed */
+        hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
+        rc = write_file(fn, hdr, raster, s);
+        goto done;
+    }
+    {
+        uint8_t *blobs = NULL;
+        uint64_t blen = 0;
+        if (xpnghip_encode_tiles((int)mode, raster, pm->w, pm->h, pxsz, &blobs, &blen)) {
+            fprintf(stderr, "xpng: GPU tile encode failed: %s\n", xpnghip_last_error());
+            goto done;
+        }
+        print_rate("encode", 1, now_ns() - t_start, pm->w * pm->h);
+        if (blen >= s) { /* libxpng.c:771-777 */
+            hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
+            rc = write_file(fn, hdr, raster, s);
+        } else rc = write_file(fn, hdr, blobs, blen);
+        free(blobs);
+    }
+done:
+    free(owned);
+    return rc;
+}
+
+_Bool xpng_store(uint64_t mode, const xpng_t *pm, const char *fn) { return xpng_store_T(0, mode, pm, fn); }
+
+_Bool xpng_load_T(uint64_t T, const char *fn, xpng_t *pm) {
+    (void)T;
+    if (!fn || !pm) return 1;
+    FILE *f = fopen(fn, "rb");
+    if (!f) return 1;
+    if (fseek(f, 0, SEEK_END)) { fclose(f); return 1; }
+    const long fl = ftell(f);
+    if (fl < 8 || fseek(f, 0, SEEK_SET)) { fclose(f); return 1; }
+    const uint64_t flen = (uint64_t)fl;
+    uint8_t *buf = malloc(flen + 16);
+    if (!buf) { fclose(f); return 1; }
+    if (fread(buf, 1, flen, f) != flen) { fclose(f); free(buf); return 1; }
+    fclose(f);
+    memset(buf + flen, 0, 16);
+    const uint64_t t_start = now_ns(); /* file read is not timed, libxpng.c:967 */
+    const uint32_t h0 = get_u32(buf), h1 = get_u32(buf + 4);
+    const uint64_t mode = h0 >> 24;
+    pm->w = (h0 & 0xFFFFFF) + 1; pm->h = (h1 & 0xFFFFFF) + 1; pm->A = (h1 >> 24) & 1;
+    if (!(mode == 1 || mode == 2 || mode == 7)) { free(buf); return 1; }
+    const int pxsz = 3 + pm->A;
+    pm->s = pm->w * pm->h * (uint64_t)pxsz;
+    pm->p = malloc(pm->s);
+    if (!pm->p) { free(buf); return 1; }
+    _Bool rc = 1;
+    if (mode == 7) {
+        if (flen >= 8 + pm->s) { memcpy(pm->p, buf + 8, pm->s); rc = 0; }
+    } else if (flen == 11u + pm->A && (buf[7] & 2)) { /* libxpng.c:976-980 */
+        for (uint64_t i = 0; i < pm->w * pm->h; i++) memcpy(pm->p + i * (uint64_t)pxsz, buf + 8, (size_t)pxsz);
+        rc = 0;
+    } else {
+        if (xpnghip_decode_tiles((int)mode, buf + 8, flen - 8, pm->w, pm->h, pxsz, pm->p))
+            fprintf(stderr, "xpng: GPU tile decode failed: %s\n", xpnghip_last_error());
+        else { print_rate("decode", 1, now_ns() - t_start, pm->w * pm->h); rc = 0; }
+    }
+    free(buf);
+    if (rc) { free(pm->p); pm->p = NULL; }
+    return rc;
+}
+
+_Bool xpng_load(const char *fn, xpng_t *pm) { return xpng_load_T(0, fn, pm); }
+
+/* libxpng.c:1004-1014: the reference ships this entry point as a stub */
+_Bool xpng_from_jpg_T(uint64_t T, const char *jpg, const char *xpng) {
+    (void)T; (void)jpg; (void)xpng;
+    puts("\nNot Implemented.\n");
+    return 1;
+}
+_Bool xpng_from_jpg(const char *jpg, const char *xpng) { return xpng_from_jpg_T(0, jpg, xpng); }

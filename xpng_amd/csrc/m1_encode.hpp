@@ -1,0 +1,263 @@
+// m1_encode.hpp -- mode-1 (XPNG_COMPRESSION_TYPE_FAST) tile ENCODE kernels for gfx950.
+//
+// Reference path restated: enc_1_th (libxpng.c:534-571) = pp_rgbx (92-140) + m1e_* (497-530) +
+// compress_block_v2 (307-427) + tile container.  The reference fuses everything into one serial loop per
+// tile; here the same bytes come out of five data-parallel stages:
+//
+//   k_chooser        sampled 4-way cost sums per tile            (pp_rgbx)
+//   k_m1_transform   per-pixel residual / zig-zag / nl / alpha   (M1ENC arithmetic) -> 5 symbol planes
+//   k_m1_streams     routing: 9 context streams + bit stream k   (pl chain, BITSTREAM_WRITE) via wave scans
+//   k_rans2_encode   one wavefront per (tile, stream): histogram, normalise, tables, 2-lane rANS, splice
+//   k_tile_sizes / k_tile_offsets / k_tile_gather                 tile blob container + concatenation
+#pragma once
+#include "common.hpp"
+
+namespace xpng {
+
+// --------------------------------------------------------------------------------------------------
+// K1  predictor chooser: reference pp_rgbx, libxpng.c:92-140.  Every 4th pixel in x and y (x%4==3,
+// y%4==3) is costed under avg / avg+G / grad / grad+G; the four sums go to sums[tile*4..] by atomics.
+// grid = tiles * strips, block = 256.
+template <int PXSZ>
+__global__ __launch_bounds__(256) void k_chooser(const uint8_t *__restrict__ raster, uint64_t bpr,
+                                                 const TileDesc *__restrict__ tiles, uint32_t t0, uint32_t strips,
+                                                 uint32_t *__restrict__ sums) {
+    const uint32_t tile = t0 + blockIdx.x / strips, strip = blockIdx.x % strips;
+    const TileDesc t = tiles[tile];
+    if (t.w < 4 || t.h < 4) return;
+    const uint32_t xs = t.w >> 2, ys = t.h >> 2;
+    const uint32_t j0 = (uint32_t)((uint64_t)ys * strip / strips), j1 = (uint32_t)((uint64_t)ys * (strip + 1) / strips);
+    const uint32_t cnt = (j1 - j0) * xs;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
+        const uint32_t j = j0 + idx / xs, i = idx - (idx / xs) * xs;
+        const uint8_t *p = raster + (uint64_t)(t.y + 4 * j + 3) * bpr + (uint64_t)(t.x + 4 * i + 3) * PXSZ;
+        const uint32_t cur = load_px<PXSZ>(p);
+        if (PXSZ == 4 && (cur >> 24) == 0) continue;  // libxpng.c:121
+        const uint32_t L = load_px<PXSZ>(p - PXSZ), U = load_px<PXSZ>(p - bpr), UL = load_px<PXSZ>(p - bpr - PXSZ);
+        int d2[3], d3[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int v = (cur >> (8 * c)) & 255, l = (L >> (8 * c)) & 255, u = (U >> (8 * c)) & 255, ul = (UL >> (8 * c)) & 255;
+            d2[c] = v - pred_avg(l, u);
+            d3[c] = v - pred_grad(l, u, ul);
+        }
+        c0 += bit_width(zz_enc(d2[0]) | zz_enc(d2[1]) | zz_enc(d2[2]));
+        c1 += bit_width(zz_enc(d2[0] - d2[1]) | zz_enc(d2[1]) | zz_enc(d2[2] - d2[1]));
+        c2 += bit_width(zz_enc(d3[0]) | zz_enc(d3[1]) | zz_enc(d3[2]));
+        c3 += bit_width(zz_enc(d3[0] - d3[1]) | zz_enc(d3[1]) | zz_enc(d3[2] - d3[1]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off);
+        c1 += __shfl_down(c1, off);
+        c2 += __shfl_down(c2, off);
+        c3 += __shfl_down(c3, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t *s = sums + (uint64_t)tile * 4;
+        if (c0) atomicAdd(s + 0, c0);
+        if (c1) atomicAdd(s + 1, c1);
+        if (c2) atomicAdd(s + 2, c2);
+        if (c3) atomicAdd(s + 3, c3);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Per-pixel arithmetic of M1ENC / M1ENC4 (libxpng.c:497-513) without the routing.  cur/L/U/UL are packed
+// pixels (r | g<<8 | b<<16 | a<<24).  Outputs: nl (or NL_NONE), zig-zag residual bytes, alpha symbol.
+template <int PXSZ>
+__device__ __forceinline__ void m1_pixel(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, bool row0, bool col0,
+                                         int useGrad, int useG, uint32_t &nl, uint32_t &zr, uint32_t &zg, uint32_t &zb,
+                                         uint32_t &za) {
+    nl = NL_NONE; zr = zg = zb = za = 0;
+    if constexpr (PXSZ == 4) {
+        const int ca = cur >> 24;
+        const int pa = (row0 || !col0) ? (int)(L >> 24) : (int)(U >> 24);  // libxpng.c:510-511: left, except in column 0
+        za = (uint32_t)zz_enc(ca - pa);
+        if (ca == 0) return;  // libxpng.c:502: invisible pixel emits alpha only
+    }
+    int d[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int v = (cur >> (8 * c)) & 255, l = (L >> (8 * c)) & 255, u = (U >> (8 * c)) & 255, ul = (UL >> (8 * c)) & 255;
+        int pred;
+        if (row0) pred = l;
+        else if (col0) pred = u;
+        else pred = useGrad ? pred_grad(l, u, ul) : pred_avg(l, u);
+        d[c] = v - pred;
+    }
+    if (useG && !row0 && !col0) { d[0] -= d[1]; d[2] -= d[1]; }  // libxpng.c:513
+    zr = (uint32_t)zz_enc(d[0]); zg = (uint32_t)zz_enc(d[1]); zb = (uint32_t)zz_enc(d[2]);
+    nl = (uint32_t)bit_width(zr | zg | zb);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K2 (generic form)  per-pixel transform straight from global memory; one thread = 4 consecutive pixels of
+// the tile in raster order, so every plane store is one aligned dword.  Works for any tile geometry
+// (including the very wide / very tall tiles of images narrower than 444 px); the LDS-staged fast form
+// below takes over for ordinary tiles.
+// grid = tiles * blocks_per_tile, block = 256 (1024 pixels per block).
+template <int PXSZ>
+__global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *__restrict__ raster, uint64_t bpr,
+                                                              const TileDesc *__restrict__ tiles, uint32_t t0,
+                                                              uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
+                                                              uint8_t *__restrict__ planes, uint64_t plane_stride) {
+    const uint32_t tile = t0 + blockIdx.x / blocks_per_tile, chunk = blockIdx.x % blocks_per_tile;
+    const TileDesc t = tiles[tile];
+    const uint32_t i0 = (chunk * 256 + threadIdx.x) * 4;
+    if (i0 >= t.n) return;
+    const int pr = pr_from_sums(sums + (uint64_t)tile * 4, PXSZ, t.w, t.h);
+    const int useGrad = (pr >> 1) & 1, useG = pr & 1;
+    uint32_t y = i0 / t.w, x = i0 - y * t.w;
+    uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+        const uint32_t i = i0 + k;
+        if (i < t.n && i > 0) {
+            const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * PXSZ;
+            const uint32_t cur = load_px<PXSZ>(p);
+            const bool row0 = y == 0, col0 = x == 0;
+            const uint32_t L = col0 ? 0u : load_px<PXSZ>(p - PXSZ);
+            const uint32_t U = row0 ? 0u : load_px<PXSZ>(p - bpr);
+            const uint32_t UL = (row0 || col0) ? 0u : load_px<PXSZ>(p - bpr - PXSZ);
+            m1_pixel<PXSZ>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
+        }
+        onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+        if (++x == t.w) { x = 0; y++; }
+    }
+    const uint64_t o = t.pbase + i0;
+    *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
+    *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
+    *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
+    *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
+    if (PXSZ == 4) *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3  stream formation.  One 1024-thread workgroup walks one tile in raster order, 1024 pixels per step.
+// Three serial couplings of the reference loop become wave-level prefix operations:
+//   (i)  pl = nl of the previous CODED pixel            -> ballot + "highest set bit below me" + carry
+//   (ii) append position inside context stream cx[pl]   -> one ballot/popcount per context (9)
+//   (iii) bit cursor of k (3*nl bits per coded pixel)   -> wave inclusive scan + cross-wave offsets,
+//        bits are OR-ed MSB-first into an LDS word window and spliced into k with a carried partial word.
+// Outputs: ctx streams + their lengths, k words + count.   grid = tiles, block = 1024.
+constexpr int ST_THREADS = 1024, ST_WAVES = ST_THREADS / 64;
+constexpr int ST_WORDS = ST_THREADS * 24 / 32 + 4;
+
+template <int PXSZ>
+__global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *__restrict__ raster, uint64_t bpr,
+                                                           const TileDesc *__restrict__ tiles, uint32_t t0,
+                                                           const uint8_t *__restrict__ planes, uint64_t plane_stride,
+                                                           uint8_t *__restrict__ scratch, uint32_t *__restrict__ ctx_n,
+                                                           uint32_t *__restrict__ k_n) {
+    const uint32_t tile = t0 + blockIdx.x;
+    const TileDesc t = tiles[tile];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t *pnl = planes + t.pbase, *pr_ = planes + plane_stride + t.pbase;
+    const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;
+    uint8_t *sc = scratch + t.sbase;
+    uint32_t *kw = reinterpret_cast<uint32_t *>(sc + off_kw(t.n));
+
+    __shared__ uint32_t s_bits[ST_WORDS];
+    __shared__ uint32_t s_run_cnt[9];
+    __shared__ uint32_t s_wave_cnt[ST_WAVES][9];
+    __shared__ uint32_t s_wave_bits[ST_WAVES];
+    __shared__ uint32_t s_wave_last[ST_WAVES];
+
+    // first pixel: 8*PXSZ raw bits at the head of k (libxpng.c:547)
+    const uint8_t *p0 = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
+    uint32_t run_bits, wbase, run_pl = 0;  // uniform across the workgroup
+    for (int j = tid; j < ST_WORDS; j += ST_THREADS) s_bits[j] = 0;
+    if (tid < 9) s_run_cnt[tid] = 0;
+    __syncthreads();
+    if (PXSZ == 4) {
+        if (tid == 0) kw[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8) | p0[3];
+        run_bits = 32; wbase = 1;
+    } else {
+        if (tid == 0) s_bits[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8);
+        run_bits = 24; wbase = 0;
+    }
+    const uint64_t lt = lanemask_lt();
+
+    for (uint32_t i0 = 0; i0 < t.n; i0 += ST_THREADS) {
+        const uint32_t i = i0 + tid;
+        const uint32_t nlv = i < t.n ? pnl[i] : NL_NONE;
+        const bool coded = nlv != NL_NONE;
+        const uint64_t mask = __ballot(coded);
+        const uint64_t lower = mask & lt;
+        // (i) previous coded nl inside the wave
+        const int src_last = mask ? 63 - __clzll((long long)mask) : 0;
+        const uint32_t wave_last = __shfl(nlv, src_last);
+        if (lane == 0) s_wave_last[wv] = mask ? wave_last : NL_NONE;
+        const int src_prev = lower ? 63 - __clzll((long long)lower) : 0;
+        const uint32_t prev_in_wave = __shfl(nlv, src_prev);
+        // (iii) bit lengths: inclusive scan inside the wave
+        const uint32_t len = coded ? 3 * nlv : 0;
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += v;
+        }
+        if (lane == 63) s_wave_bits[wv] = incl;
+        __syncthreads();  // (A) wave_last / wave_bits visible
+
+        uint32_t carry = run_pl, bit_base = 0, bits_total = 0, new_run_pl = run_pl;
+        for (int w2 = 0; w2 < ST_WAVES; w2++) {
+            const uint32_t wl = s_wave_last[w2], wb = s_wave_bits[w2];
+            if (w2 < (int)wv) { if (wl != NL_NONE) carry = wl; bit_base += wb; }
+            if (wl != NL_NONE) new_run_pl = wl;
+            bits_total += wb;
+        }
+        const uint32_t pl = lower ? prev_in_wave : carry;
+        // (ii) rank inside the context stream
+        uint32_t my_rank = 0, my_cnt = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 9; c++) {
+            const uint64_t m = __ballot(coded && pl == c);
+            if (pl == c) my_rank = (uint32_t)__popcll(m & lt);
+            if (lane == c) my_cnt = (uint32_t)__popcll(m);
+        }
+        if (lane < 9) s_wave_cnt[wv][lane] = my_cnt;
+        __syncthreads();  // (B) per-wave context counts visible
+
+        if (coded) {
+            uint32_t base = s_run_cnt[pl];
+            for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave_cnt[w2][pl];
+            sc[off_ctx(t.n, (int)pl) + base + my_rank] = (uint8_t)nlv;
+            if (nlv) {
+                const uint32_t v = ((uint32_t)pr_[i] << (2 * nlv)) | ((uint32_t)pg[i] << nlv) | (uint32_t)pb[i];
+                const uint32_t ob = (run_bits & 31) + bit_base + (incl - len);
+                const uint32_t wi = ob >> 5;
+                const int sh = 32 - (int)(ob & 31) - (int)len;
+                if (sh >= 0) atomicOr(&s_bits[wi], v << sh);
+                else { atomicOr(&s_bits[wi], v >> (-sh)); atomicOr(&s_bits[wi + 1], v << (32 + sh)); }
+            }
+        }
+        __syncthreads();  // (C) bit window complete
+
+        const uint32_t nfull = ((run_bits & 31) + bits_total) >> 5;
+        uint32_t keep = 0, carry_word = 0;
+        if (tid < ST_WORDS) keep = s_bits[tid];
+        if (tid == 0) carry_word = s_bits[nfull];
+        uint32_t tot_c = 0;
+        if (tid < 9) { for (int w2 = 0; w2 < ST_WAVES; w2++) tot_c += s_wave_cnt[w2][tid]; }
+        __syncthreads();  // (D) everyone has read the window / counts
+        if (tid < nfull) kw[wbase + tid] = keep;
+        if (tid < ST_WORDS) s_bits[tid] = tid == 0 ? carry_word : 0;
+        if (tid < 9) s_run_cnt[tid] += tot_c;
+        run_bits += bits_total; wbase += nfull; run_pl = new_run_pl;
+        // the next iteration's barrier (A) orders these LDS writes before their next use
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t words = wbase;
+        if (run_bits & 31) { kw[wbase] = s_bits[0]; words++; }  // BITSTREAM_END: tail is already left-aligned
+        k_n[tile] = words;
+    }
+    if (tid < 9) ctx_n[(uint64_t)tile * 9 + tid] = s_run_cnt[tid];
+}
+
+}  // namespace xpng

@@ -1,0 +1,328 @@
+// xpng_hip.hip -- C-ABI of libxpng_hip.so (include/xpng_hip.h): context, launches, host-buffer wrappers.
+// gfx950 only.  No CPU fallback: every compute entry point fails when HIP has no device.
+#include "../../include/xpng_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "m1_decode.hpp"
+#include "m1_encode.hpp"
+#include "rans2.hpp"
+#include "tile_container.hpp"
+
+using namespace xpng;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return 1; }
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+extern "C" int xpnghip_abi_version(void) { return XPNGHIP_ABI_VERSION; }
+extern "C" const char *xpnghip_last_error(void) { return g_err.c_str(); }
+extern "C" int xpnghip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- tile table (reference compute_props_of_each_tile, libxpng.c:51-83) ---------------------------------
+static void split_axis(uint64_t len, uint64_t base, uint64_t &count, uint64_t &first, uint64_t &second) {
+    const uint64_t rem = len % base;
+    count = len / base; first = base + rem; second = base;
+    if (rem > base / 2) { count++; second = first / 2; first = second + (first & 1); }
+}
+static void build_tiles(uint64_t W, uint64_t H, std::vector<TileDesc> &out) {
+    uint64_t nx = 1, ny = 1, w0 = W, w1 = 0, bw = 0, h0 = H, h1 = 0, bh = 0;
+    if (W * H > TILE_AREA) {
+        if (W < 444) { bw = W; bh = TILE_AREA / W; }
+        else if (H < 444) { bh = H; bw = TILE_AREA / H; }
+        else bw = bh = 444;
+        split_axis(W, bw, nx, w0, w1);
+        split_axis(H, bh, ny, h0, h1);
+    }
+    out.clear();
+    out.reserve(nx * ny);
+    uint64_t pbase = 0, sbase = 0;
+    for (uint64_t j = 0; j < ny; j++) {
+        const uint64_t y = j == 0 ? 0 : (j == 1 ? h0 : h0 + h1 + (j - 2) * bh), th = j == 0 ? h0 : (j == 1 ? h1 : bh);
+        for (uint64_t i = 0; i < nx; i++) {
+            TileDesc t{};
+            t.x = (uint32_t)(i == 0 ? 0 : (i == 1 ? w0 : w0 + w1 + (i - 2) * bw));
+            t.w = (uint32_t)(i == 0 ? w0 : (i == 1 ? w1 : bw));
+            t.y = (uint32_t)y; t.h = (uint32_t)th;
+            t.n = t.w * t.h;
+            t.pbase = pbase; t.sbase = sbase;
+            pbase += rup(t.n + 8, 256);
+            sbase += tile_scratch_bytes(t.n);
+            out.push_back(t);
+        }
+    }
+}
+
+struct xpnghip_ctx {
+    int device = 0;
+    uint64_t W = 0, H = 0;
+    int pxsz = 0;
+    uint32_t spt = 0;  // streams per tile: 9 (+1 alpha)
+    std::vector<TileDesc> tiles;
+    uint64_t plane_stride = 0, scratch_bytes = 0, ws_bytes = 0;
+    uint32_t max_n = 0;
+    TileDesc *d_tiles = nullptr;
+    uint8_t *d_planes = nullptr, *d_scratch = nullptr;
+    uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
+    uint64_t *d_off = nullptr;
+    uint64_t *h_total = nullptr;  // pinned
+    hipStream_t stream = nullptr;
+    // host-buffer wrappers keep their own device raster / blob buffers here
+    uint8_t *d_raster = nullptr, *d_blobs = nullptr;
+    uint64_t last_t0 = 0, last_t1 = 0;
+    DecodeWs dec;
+};
+
+extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz,
+                    c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_raster, c->d_blobs};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    decode_ws_free(c->dec);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int xpnghip_ctx_create(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz) {
+    if (!out || !w || !h || w > (1u << 24) || h > (1u << 24) || (pxsz != 3 && pxsz != 4)) return fail("bad arguments");
+    if (xpnghip_device_count() <= device || device < 0) return fail("no such HIP device (libxpng_hip has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    xpnghip_ctx *c = new xpnghip_ctx();
+    c->device = device; c->W = w; c->H = h; c->pxsz = pxsz; c->spt = pxsz == 4 ? 10 : 9;
+    build_tiles(w, h, c->tiles);
+    const uint64_t N = c->tiles.size();
+    const TileDesc &last = c->tiles.back();
+    c->plane_stride = last.pbase + rup(last.n + 8, 256);
+    c->scratch_bytes = last.sbase + tile_scratch_bytes(last.n);
+    for (auto &t : c->tiles) c->max_n = t.n > c->max_n ? t.n : c->max_n;
+#define ALLOC(ptr, bytes)                                                                          \
+    do {                                                                                           \
+        if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) {                                   \
+            xpnghip_ctx_destroy(c);                                                                \
+            return fail("hipMalloc failed for " #ptr);                                             \
+        }                                                                                          \
+        c->ws_bytes += (bytes);                                                                    \
+    } while (0)
+    ALLOC(c->d_tiles, N * sizeof(TileDesc));
+    ALLOC(c->d_planes, 5 * c->plane_stride);
+    ALLOC(c->d_scratch, c->scratch_bytes);
+    ALLOC(c->d_sums, N * 16);
+    ALLOC(c->d_ctx_n, N * 9 * 4);
+    ALLOC(c->d_k_n, N * 4);
+    ALLOC(c->d_blk_sz, N * 10 * 4);
+    ALLOC(c->d_tile_sz, N * 4);
+    ALLOC(c->d_tile_hdr, N * 4);
+    ALLOC(c->d_off, (N + 1) * 8);
+#undef ALLOC
+    if (hipHostMalloc((void **)&c->h_total, 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipMemcpy(c->d_tiles, c->tiles.data(), N * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess) {
+        xpnghip_ctx_destroy(c);
+        return fail("context setup failed");
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" uint64_t xpnghip_ctx_tile_count(const xpnghip_ctx *c) { return c ? c->tiles.size() : 0; }
+extern "C" int xpnghip_ctx_tile(const xpnghip_ctx *c, uint64_t i, uint64_t xywh[4]) {
+    if (!c || i >= c->tiles.size()) return 1;
+    xywh[0] = c->tiles[i].x; xywh[1] = c->tiles[i].y; xywh[2] = c->tiles[i].w; xywh[3] = c->tiles[i].h;
+    return 0;
+}
+extern "C" uint64_t xpnghip_ctx_blob_bound(const xpnghip_ctx *c, uint64_t t0, uint64_t t1) {
+    uint64_t b = 0;
+    for (uint64_t i = t0; c && i < t1 && i < c->tiles.size(); i++) b += (uint64_t)c->tiles[i].n * c->pxsz + 4;
+    return b + 16;
+}
+extern "C" uint64_t xpnghip_ctx_workspace_bytes(const xpnghip_ctx *c) { return c ? c->ws_bytes : 0; }
+
+static int check_range(const xpnghip_ctx *c, uint64_t t0, uint64_t t1) {
+    if (!c) return fail("null context");
+    if (t0 >= t1 || t1 > c->tiles.size()) return fail("bad tile range");
+    return 0;
+}
+
+// chooser + transform (BASELINE config 2).  Launch only; no sync.
+template <int PXSZ>
+static int launch_transform(xpnghip_ctx *c, const uint8_t *d_raster, uint32_t t0, uint32_t t1, hipStream_t s) {
+    const uint32_t cnt = t1 - t0;
+    const uint64_t bpr = c->W * PXSZ;
+    uint32_t max_n = 0;
+    for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
+    HIPCHK(hipMemsetAsync(c->d_sums + (uint64_t)t0 * 4, 0, (uint64_t)cnt * 16, s));
+    const uint32_t strips = 8;
+    k_chooser<PXSZ><<<cnt * strips, 256, 0, s>>>(d_raster, bpr, c->d_tiles, t0, strips, c->d_sums);
+    const uint32_t bpt = (max_n + 1023) / 1024;
+    k_m1_transform_generic<PXSZ><<<cnt * bpt, 256, 0, s>>>(d_raster, bpr, c->d_tiles, t0, bpt, c->d_sums, c->d_planes, c->plane_stride);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int xpnghip_m1_transform_device(xpnghip_ctx *c, const void *d_raster, uint64_t t0, uint64_t t1, void *stream) {
+    if (check_range(c, t0, t1)) return 1;
+    if ((uintptr_t)d_raster & 15) return fail("device raster must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->last_t0 = t0; c->last_t1 = t1;
+    return c->pxsz == 4 ? launch_transform<4>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, s)
+                        : launch_transform<3>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, s);
+}
+
+template <int PXSZ>
+static int launch_encode_m1(xpnghip_ctx *c, const uint8_t *d_raster, uint32_t t0, uint32_t t1, uint8_t *d_blobs, hipStream_t s) {
+    const uint32_t cnt = t1 - t0;
+    const uint64_t bpr = c->W * PXSZ;
+    if (launch_transform<PXSZ>(c, d_raster, t0, t1, s)) return 1;
+    k_m1_streams<PXSZ><<<cnt, ST_THREADS, 0, s>>>(d_raster, bpr, c->d_tiles, t0, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    k_rans2_encode<<<cnt * c->spt, 64, 0, s>>>(c->d_tiles, t0, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz);
+    k_tile_sizes<<<(cnt + 255) / 256, 256, 0, s>>>(c->d_tiles, t0, cnt, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
+    k_tile_offsets<<<1, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off);
+    k_tile_gather<<<cnt, 256, 0, s>>>(d_raster, bpr, PXSZ, c->d_tiles, t0, c->spt, c->d_scratch, c->d_k_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, d_blobs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_total, c->d_off + cnt, 8, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+extern "C" int xpnghip_encode_device(xpnghip_ctx *c, int mode, const void *d_raster, uint64_t t0, uint64_t t1,
+                                     void *d_blobs, uint64_t *blobs_len, void *stream) {
+    if (check_range(c, t0, t1)) return 1;
+    if (mode != 1) return fail("only mode 1 is implemented on the device in this build");
+    if ((uintptr_t)d_raster & 15 || (uintptr_t)d_blobs & 15) return fail("device buffers must be 16-byte aligned");
+    if (c->pxsz == 4)
+        for (uint64_t i = t0; i < t1; i++)
+            if (c->tiles[i].w < 4 || c->tiles[i].h < 4) return fail("RGBA tile narrower than 4 px: undefined in the reference; store level 7");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->last_t0 = t0; c->last_t1 = t1;
+    const int rc = c->pxsz == 4 ? launch_encode_m1<4>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, (uint8_t *)d_blobs, s)
+                                : launch_encode_m1<3>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, (uint8_t *)d_blobs, s);
+    if (rc) return rc;
+    if (blobs_len) {
+        HIPCHK(hipStreamSynchronize(s));
+        *blobs_len = *c->h_total;
+    }
+    return 0;
+}
+extern "C" uint64_t xpnghip_ctx_last_blobs_len(xpnghip_ctx *c) { return c ? *c->h_total : 0; }
+
+extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
+                                     const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
+    if (check_range(c, t0, t1)) return 1;
+    if (mode != 1) return fail("only mode 1 is implemented on the device in this build");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return decode_m1_launch(c->dec, c->tiles, c->d_tiles, c->W, c->pxsz, (const uint8_t *)d_blobs, blobs_len, tile_off,
+                            (uint32_t)t0, (uint32_t)t1, (uint8_t *)d_raster, s, g_err);
+}
+
+// ---- host-buffer wrappers ------------------------------------------------------------------------------
+static std::mutex g_mu;
+static xpnghip_ctx *g_cached = nullptr;
+static xpnghip_ctx *cached_ctx(uint64_t w, uint64_t h, int pxsz) {
+    if (g_cached && (g_cached->W != w || g_cached->H != h || g_cached->pxsz != pxsz)) { xpnghip_ctx_destroy(g_cached); g_cached = nullptr; }
+    if (!g_cached && xpnghip_ctx_create(&g_cached, 0, w, h, pxsz)) return nullptr;
+    return g_cached;
+}
+
+extern "C" int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz,
+                                    uint8_t **blobs, uint64_t *blobs_len) {
+    if (!raster || !blobs || !blobs_len) return fail("null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    xpnghip_ctx *c = cached_ctx(w, h, pxsz);
+    if (!c) return 1;
+    const uint64_t s = w * h * (uint64_t)pxsz, N = c->tiles.size(), bound = xpnghip_ctx_blob_bound(c, 0, N);
+    if (!c->d_raster) HIPCHK(hipMalloc((void **)&c->d_raster, s + 64));
+    if (!c->d_blobs) HIPCHK(hipMalloc((void **)&c->d_blobs, bound + 64));
+    HIPCHK(hipMemcpyAsync(c->d_raster, raster, s, hipMemcpyHostToDevice, c->stream));
+    uint64_t len = 0;
+    if (xpnghip_encode_device(c, mode, c->d_raster, 0, N, c->d_blobs, &len, nullptr)) return 1;
+    uint8_t *out = (uint8_t *)malloc(len ? len : 1);
+    if (!out) return fail("malloc failed");
+    HIPCHK(hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost));
+    *blobs = out; *blobs_len = len;
+    return 0;
+}
+
+extern "C" int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
+                                    int pxsz, uint8_t *raster) {
+    if (!raster || !blobs) return fail("null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    xpnghip_ctx *c = cached_ctx(w, h, pxsz);
+    if (!c) return 1;
+    const uint64_t s = w * h * (uint64_t)pxsz, N = c->tiles.size();
+    std::vector<uint64_t> off(N);
+    uint64_t o = 0;
+    for (uint64_t i = 0; i < N; i++) {  // serial size walk, libxpng.c:982
+        if (o + 4 > blobs_len) return fail("truncated file: tile table runs past the end");
+        uint32_t h0; memcpy(&h0, blobs + o, 4);
+        off[i] = o; o += h0 & 0xFFFFFF;
+    }
+    if (o > blobs_len) return fail("truncated file: last tile runs past the end");
+    if (!c->d_raster) HIPCHK(hipMalloc((void **)&c->d_raster, s + 64));
+    uint8_t *d_in = nullptr;
+    HIPCHK(hipMalloc((void **)&d_in, blobs_len + 64));
+    int rc = 1;
+    if (hipMemcpyAsync(d_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+        !xpnghip_decode_device(c, mode, d_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr) &&
+        hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(raster, c->d_raster, s, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = 0;
+    else if (g_err.empty()) g_err = "decode failed";
+    (void)hipFree(d_in);
+    return rc;
+}
+
+// ---- introspection for parity tests ----------------------------------------------------------------------
+extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, void *out, uint64_t cap) {
+    if (!c || tile >= c->tiles.size() || !out) return -1;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    const TileDesc &t = c->tiles[tile];
+    const uint8_t *src = nullptr;
+    uint64_t bytes = 0;
+    uint32_t tmp[16];
+    auto d2h = [&](void *dst, const void *s, uint64_t b) { return hipMemcpy(dst, s, b, hipMemcpyDeviceToHost) == hipSuccess; };
+    if (what == 0) {
+        if (!d2h(tmp, c->d_sums + tile * 4, 16)) return -1;
+        int m = 0; uint32_t r = tmp[0];
+        for (int k = 1; k < 4; k++) if (tmp[k] < r) { m = k; r = tmp[k]; }
+        uint8_t pr = (t.w < 4 || t.h < 4) ? 0 : (uint8_t)((c->pxsz & 4) | m);
+        if (cap < 1) return -1;
+        *(uint8_t *)out = pr;
+        return 1;
+    } else if (what >= 1 && what <= 5) {
+        src = c->d_planes + (uint64_t)(what - 1) * c->plane_stride + t.pbase; bytes = t.n;
+    } else if (what >= 10 && what <= 18) {
+        if (!d2h(tmp, c->d_ctx_n + tile * 9, 36)) return -1;
+        src = c->d_scratch + t.sbase + off_ctx(t.n, what - 10); bytes = tmp[what - 10];
+    } else if (what == 19) {
+        if (!d2h(tmp, c->d_k_n + tile, 4)) return -1;
+        src = c->d_scratch + t.sbase + off_kw(t.n); bytes = 4ull * tmp[0];
+    } else if (what >= 20 && what <= 29) {
+        if ((uint32_t)(what - 20) >= c->spt) return 0;
+        if (!d2h(tmp, c->d_blk_sz + tile * 10, 40)) return -1;
+        src = c->d_scratch + t.sbase + off_blk(t.n, what - 20); bytes = tmp[what - 20];
+    } else if (what == 30) {
+        src = (const uint8_t *)(c->d_sums + tile * 4); bytes = 16;
+    } else return -1;
+    if (bytes > cap) return -1;
+    if (bytes && !d2h(out, src, bytes)) return -1;
+    return (int64_t)bytes;
+}
