@@ -21,14 +21,7 @@ def manifest():
         return json.load(f)
 
 
-def load_seven(path):
-    """.7 file -> (h, w, ch) uint8 raster (reference 7/libseven.c:18-36)."""
-    import struct
-    b = open(path, "rb").read()
-    h0, h1 = struct.unpack("<II", b[:8])
-    w, h, a = (h0 & 0xFFFFFF) + 1, (h1 & 0xFFFFFF) + 1, (h1 >> 24) & 1
-    assert h0 >> 24 == 7 and len(b) == 8 + w * h * (3 + a)
-    return np.frombuffer(b, dtype=np.uint8, offset=8).reshape(h, w, 3 + a).copy()
+from xpng_amd.synth import load_seven  # noqa: E402,F401
 
 
 def golden_raster(name, ent):

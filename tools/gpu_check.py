@@ -160,7 +160,7 @@ def cases(level):
             r = po.normalize_rgba(r)
             yield "special_" + n, r
         gold = os.path.join(ROOT, "tests", "golden")
-        from tests.conftest import load_seven
+        from xpng_amd.synth import load_seven
         for f in sorted(os.listdir(gold)):
             if f.endswith(".7"):
                 yield f[:-2], load_seven(os.path.join(gold, f))

@@ -126,6 +126,17 @@ def to_seven_bytes(raster: np.ndarray) -> bytes:
     return seven_header(w, h, ch == 4) + raster.tobytes()
 
 
+def load_seven(path: str) -> np.ndarray:
+    """.7 file -> (h, w, ch) uint8 raster (reference 7/libseven.c:18-36)."""
+    import struct
+    b = open(path, "rb").read()
+    h0, h1 = struct.unpack("<II", b[:8])
+    w, h, a = (h0 & 0xFFFFFF) + 1, (h1 & 0xFFFFFF) + 1, (h1 >> 24) & 1
+    if h0 >> 24 != 7 or len(b) != 8 + w * h * (3 + a):
+        raise ValueError(f"{path}: not a .7 file")
+    return np.frombuffer(b, dtype=np.uint8, offset=8).reshape(h, w, 3 + a).copy()
+
+
 def special_cases():
     """Named rasters that force the rarely taken branches (normalisation rewrite, opaque alpha
     drop, mixed gray / colour / single-colour tiles, raw gray tiles)."""
