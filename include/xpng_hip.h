@@ -49,6 +49,11 @@ int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uin
 typedef struct xpnghip_ctx xpnghip_ctx;
 
 int xpnghip_ctx_create(xpnghip_ctx **ctx, int device, uint64_t w, uint64_t h, int pxsz);
+/* Same, sized for up to `batch` rasters of this geometry per launch.  The entropy stage is one serial chain per
+ * (tile, stream), so a single 4096^2 image (81 tiles) cannot fill 256 CUs; a batched launch runs the chains of all
+ * images side by side (virtual tile = image * N + tile) at the latency of one image. */
+int xpnghip_ctx_create_batch(xpnghip_ctx **ctx, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch);
+uint32_t xpnghip_ctx_batch(const xpnghip_ctx *ctx);
 void xpnghip_ctx_destroy(xpnghip_ctx *ctx);
 uint64_t xpnghip_ctx_tile_count(const xpnghip_ctx *ctx);
 /* tile i -> {x, y, w, h} (pixels); returns non-zero if i is out of range */
@@ -64,11 +69,20 @@ uint64_t xpnghip_ctx_workspace_bytes(const xpnghip_ctx *ctx);
 int xpnghip_encode_device(xpnghip_ctx *ctx, int mode, const void *d_raster, uint64_t t0, uint64_t t1,
                           void *d_blobs, uint64_t *blobs_len, void *stream);
 uint64_t xpnghip_ctx_last_blobs_len(xpnghip_ctx *ctx);
+/* Batched form: nimg <= batch device rasters in, nimg device blob buffers out (host arrays of device pointers);
+ * blobs_len, if not NULL, receives nimg lengths after one stream sync. */
+int xpnghip_encode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d_rasters, uint32_t nimg, uint64_t t0,
+                                uint64_t t1, void *const *d_blobs, uint64_t *blobs_len, void *stream);
+uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *ctx, uint32_t img);
 
 /* Decode tiles [t0, t1).  d_blobs holds their concatenated blobs (device); tile_off[i - t0] is the byte
  * offset of tile i's blob inside d_blobs (host array from the serial size walk, libxpng.c:982). */
 int xpnghip_decode_device(xpnghip_ctx *ctx, int mode, const void *d_blobs, uint64_t blobs_len,
                           const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream);
+
+/* Batched form: tile_off holds nimg * (t1 - t0) offsets, image-major, each relative to its image's blob buffer. */
+int xpnghip_decode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d_blobs, uint32_t nimg,
+                                const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *const *d_rasters, void *stream);
 
 /* Stage-only run for BASELINE config 2: predictor chooser + per-pixel transform (libxpng.c:92-140 and
  * the arithmetic of 497-519) over tiles [t0, t1); symbol planes stay in the context's workspace. */

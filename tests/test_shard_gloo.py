@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the multi-GPU sharding rule (contiguous tile ranges + gatherv to rank 0) reproduces
+the single-process concatenation.  The per-rank blobs come from the oracle here (no GPU in this container); on the
+GPU box the same shard.py code moves blobs produced by the HIP codec over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    from xpng_amd.shard import band_rows, gather_blobs, tile_ranges
+    from xpng_amd.synth import synth_raster
+    W, H = 1500, 1200
+    tiles = po.tile_table(W, H, 4)
+    t0, t1 = tile_ranges(len(tiles), world)[rank]
+    y0, y1 = band_rows(tiles, t0, t1)
+    # the rank materialises only its band; tile coordinates stay global
+    band = synth_raster("photo", W, y1 - y0, True, y0=y0)
+    full = np.zeros((H, W, 4), np.uint8)
+    full[y0:y1] = band
+    blob = b"".join(po.encode_tile(1, full, t) for t in tiles[t0:t1])
+    local = torch.from_numpy(np.frombuffer(blob, np.uint8).copy())
+    out, lens = gather_blobs(local, len(blob))
+    if rank == 0:
+        q.put((out.numpy().tobytes(), lens))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_process_encode():
+    from oracle import pyoracle as po
+    from xpng_amd.synth import synth_raster
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, lens = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = po.encode_tiles(1, synth_raster("photo", 1500, 1200, True))
+    assert got == whole and sum(lens) == len(whole) and len(lens) == 2
+
+
+def test_ranges_cover_all_tiles_once():
+    from xpng_amd.shard import band_rows, tile_ranges, weighted_tile_ranges
+    from oracle import pyoracle as po
+    for n, g in [(1369, 8), (81, 8), (3, 8), (1, 2), (666, 4)]:
+        r = tile_ranges(n, g)
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    tiles = po.tile_table(16384, 16384, 4)
+    assert len(tiles) == 1369
+    r = weighted_tile_ranges(tiles, 8)
+    assert len(r) == 8 and r[0][0] == 0 and r[-1][1] == 1369 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    px = [sum(t[2] * t[3] for t in tiles[a:b]) for a, b in r]
+    assert max(px) / min(px) < 1.1
+    y0, y1 = band_rows(tiles, *tile_ranges(1369, 8)[3])
+    assert 0 < y0 < y1 <= 16384

@@ -19,6 +19,8 @@ HIP_SYMBOLS = [
     "xpnghip_decode_tiles", "xpnghip_ctx_create", "xpnghip_ctx_destroy", "xpnghip_ctx_tile_count",
     "xpnghip_ctx_tile", "xpnghip_ctx_blob_bound", "xpnghip_ctx_workspace_bytes", "xpnghip_encode_device",
     "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
+    "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
+    "xpnghip_decode_device_batch",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -61,6 +63,16 @@ def hip_lib():
         L.xpnghip_decode_tiles.argtypes = [C.c_int, vp, u64, u64, u64, C.c_int, vp]
         L.xpnghip_ctx_create.restype = C.c_int
         L.xpnghip_ctx_create.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int]
+        L.xpnghip_ctx_create_batch.restype = C.c_int
+        L.xpnghip_ctx_create_batch.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int, C.c_uint32]
+        L.xpnghip_ctx_batch.restype = C.c_uint32
+        L.xpnghip_ctx_batch.argtypes = [vp]
+        L.xpnghip_encode_device_batch.restype = C.c_int
+        L.xpnghip_encode_device_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.c_uint32, u64, u64, C.POINTER(vp), C.POINTER(u64), vp]
+        L.xpnghip_ctx_last_blobs_len_at.restype = u64
+        L.xpnghip_ctx_last_blobs_len_at.argtypes = [vp, C.c_uint32]
+        L.xpnghip_decode_device_batch.restype = C.c_int
+        L.xpnghip_decode_device_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.c_uint32, C.POINTER(u64), u64, u64, C.POINTER(vp), vp]
         L.xpnghip_ctx_destroy.restype = None
         L.xpnghip_ctx_destroy.argtypes = [vp]
         L.xpnghip_ctx_tile_count.restype = u64
@@ -159,11 +171,11 @@ class Context:
 
     FETCH = {"pr": 0, "nl": 1, "r": 2, "g": 3, "b": 4, "a": 5, "k": 19, "sums": 30}
 
-    def __init__(self, w: int, h: int, pxsz: int, device: int = 0):
-        self.w, self.h, self.pxsz, self.device = w, h, pxsz, device
+    def __init__(self, w: int, h: int, pxsz: int, device: int = 0, batch: int = 1):
+        self.w, self.h, self.pxsz, self.device, self.batch = w, h, pxsz, device, batch
         self._h = C.c_void_p()
-        if hip_lib().xpnghip_ctx_create(C.byref(self._h), device, w, h, pxsz):
-            raise XpngError("xpnghip_ctx_create: " + _err())
+        if hip_lib().xpnghip_ctx_create_batch(C.byref(self._h), device, w, h, pxsz, batch):
+            raise XpngError("xpnghip_ctx_create_batch: " + _err())
         self.n_tiles = hip_lib().xpnghip_ctx_tile_count(self._h)
 
     def close(self):
@@ -199,6 +211,30 @@ class Context:
         if rc:
             raise XpngError("xpnghip_encode_device: " + _err())
         return n.value
+
+    def encode_device_batch(self, mode, d_rasters, d_blobs, t0=0, t1=None, stream=0, sync=True):
+        """d_rasters / d_blobs: sequences of device pointers (one per image, <= batch).  Returns the list of blob lengths
+        (sync=True) or None."""
+        k = len(d_rasters)
+        ins, outs, lens = (C.c_void_p * k)(*d_rasters), (C.c_void_p * k)(*d_blobs), (C.c_uint64 * k)()
+        rc = hip_lib().xpnghip_encode_device_batch(self._h, mode, ins, k, t0, self.n_tiles if t1 is None else t1, outs,
+                                                   lens if sync else None, stream)
+        if rc:
+            raise XpngError("xpnghip_encode_device_batch: " + _err())
+        return list(lens) if sync else None
+
+    def decode_device_batch(self, mode, d_blobs, tile_offs, d_rasters, t0=0, t1=None, stream=0):
+        """tile_offs: per image, the list of blob start offsets of tiles [t0, t1) inside that image's blob buffer."""
+        k = len(d_blobs)
+        t1 = self.n_tiles if t1 is None else t1
+        flat = [o for offs in tile_offs for o in offs]
+        assert len(flat) == k * (t1 - t0)
+        key = (tuple(flat), t0, t1)
+        if getattr(self, "_off_key", None) != key:
+            self._off_key, self._off_arr = key, (C.c_uint64 * len(flat))(*flat)
+        ins, outs = (C.c_void_p * k)(*d_blobs), (C.c_void_p * k)(*d_rasters)
+        if hip_lib().xpnghip_decode_device_batch(self._h, mode, ins, k, self._off_arr, t0, t1, outs, stream):
+            raise XpngError("xpnghip_decode_device_batch: " + _err())
 
     def last_blobs_len(self) -> int:
         return hip_lib().xpnghip_ctx_last_blobs_len(self._h)

@@ -14,10 +14,15 @@ constexpr int WAVE = 64;
 struct TileDesc {
     uint32_t x, y, w, h;  // top-left pixel and size inside the raster
     uint32_t n;           // w*h
-    uint32_t _pad;
+    uint32_t img;         // image index inside the batch (rasters[img], blobs[img])
     uint64_t pbase;       // first index of this tile in each symbol plane (multiple of 256)
     uint64_t sbase;       // byte offset of this tile's stream scratch (multiple of 256)
 };
+
+// A launch covers tiles [t0, t0 + cnt) of EVERY image of the batch.  Work item j in [0, B*cnt) maps to image j / cnt and
+// to entry vtile(j) of the (B * N)-entry tile table.
+struct TileSel { uint32_t t0, cnt, N; };
+__host__ __device__ inline uint32_t vtile(const TileSel &s, uint32_t j) { return (j / s.cnt) * s.N + s.t0 + (j % s.cnt); }
 
 // Stream-scratch layout of one tile, all offsets relative to TileDesc::sbase and derived from n only,
 // so that host and device agree without a table.  Capacities are worst cases:
@@ -25,7 +30,7 @@ struct TileDesc {
 //   k bit stream    : 8*pxsz bits + <= 24 bits/pixel
 //   rANS v2 block   : 12 B header + ceil(n*pb/32) words + 16 B states + table (<= 256*16 bits)
 __host__ __device__ inline uint64_t rup(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
-__host__ __device__ inline uint64_t ctx_cap(uint32_t n) { return rup((uint64_t)n + 16, 256); }
+__host__ __device__ inline uint64_t ctx_cap(uint32_t n) { return rup((uint64_t)n + 64, 256); }
 __host__ __device__ inline uint64_t kw_cap(uint32_t n) { return rup(3ull * n + 64, 256); }
 __host__ __device__ inline uint64_t ctxblk_cap(uint32_t n) { return rup(3ull * n / 2 + 128, 256); }
 __host__ __device__ inline uint64_t alphablk_cap(uint32_t n) { return rup(2ull * n + 1280, 256); }
@@ -79,5 +84,9 @@ constexpr uint64_t RANS_L = 1ull << 31;  // reference RANS64_L, libxpng.c:153
 __device__ __forceinline__ uint32_t swap_pair(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
 }
+
+// force a wave-uniform value into an SGPR (loop cursors derived from ballots stay scalar: SALU arithmetic and
+// s_cbranch instead of VALU + exec-mask branches)
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 }  // namespace xpng

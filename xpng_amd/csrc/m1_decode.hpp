@@ -12,6 +12,7 @@
 //   k_dec_resid       bit cursor = scan of 3*nl; residual extraction from k; zig-zag / green add-back (804-813)
 //   k_dec_recon       causal prediction from reconstructed L/U/UL: anti-diagonal wavefront, one row per thread
 #pragma once
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -20,7 +21,7 @@
 namespace xpng {
 
 struct DecTile {  // per-tile parse result (device)
-    uint64_t off;       // byte offset of the tile blob in d_blobs
+    const uint8_t *blob;  // the tile blob (inside its image's blob buffer)
     uint32_t type;      // tile type byte (0 = raw rows)
     uint32_t kbytes;    // bytes of k words
     uint32_t blk_off[10];  // block offsets relative to the blob start
@@ -30,6 +31,10 @@ struct DecTile {  // per-tile parse result (device)
 
 struct DecodeWs {
     uint64_t cap_tiles = 0, cap_plane = 0;
+    std::vector<uint64_t> last_off;      // tile offsets already resident in d_off (skip the upload when unchanged)
+    uint32_t last_t0 = 0;
+    hipStream_t side = nullptr;          // alpha branch runs beside the nl-context branch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DecTile *d_info = nullptr;
     uint64_t *d_off = nullptr;
     uint8_t *d_ctxsym = nullptr, *d_asym = nullptr, *d_alpha = nullptr, *d_nlseq = nullptr;
@@ -38,7 +43,10 @@ struct DecodeWs {
 inline void decode_ws_free(DecodeWs &w) {
     void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid};
     for (void *q : p) if (q) (void)hipFree(q);
-    w = DecodeWs();
+    if (w.side) (void)hipStreamDestroy(w.side);
+    if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
+    if (w.ev_join) (void)hipEventDestroy(w.ev_join);
+    w = DecodeWs();  // (also clears last_off)
 }
 
 // unaligned-safe little-endian u32 load from global memory (tile blobs are only byte-aligned after a raw RGB tile)
@@ -68,13 +76,13 @@ struct BitR {
 };
 
 // --------------------------------------------------------------------------------------------------
-__global__ void k_dec_parse(const uint8_t *__restrict__ blobs, const uint64_t *__restrict__ off, uint32_t cnt,
-                            uint32_t spt, DecTile *__restrict__ info) {
+__global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off, uint32_t cnt,
+                            uint32_t total, uint32_t spt, DecTile *__restrict__ info) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cnt) return;
+    if (j >= total) return;
     DecTile d{};
-    d.off = off[j];
-    const uint8_t *f = blobs + d.off;
+    d.blob = blobs[j / cnt] + off[j];
+    const uint8_t *f = d.blob;
     const uint32_t h0 = ld32u(f);
     d.type = h0 >> 24;
     if (d.type != 0) {
@@ -94,25 +102,43 @@ __global__ void k_dec_parse(const uint8_t *__restrict__ blobs, const uint64_t *_
 }
 
 // --------------------------------------------------------------------------------------------------
-// one v2 block -> symbols (decompress_block_v2, libxpng.c:429-493).  Single-wave workgroup.
-// LDS: slot2sym[32768] bytes, fc[256] (F | cum<<16), F32/cum scratch.
-__global__ __launch_bounds__(64) void k_rans2_decode(const uint8_t *__restrict__ blobs, const DecTile *__restrict__ info,
-                                                     const TileDesc *__restrict__ tiles, uint32_t t0, uint32_t spt,
-                                                     uint8_t *__restrict__ ctxsym, uint8_t *__restrict__ asym) {
-    __shared__ uint8_t slot2sym[1 << 15];
+// one v2 block -> symbols (decompress_block_v2, libxpng.c:429-493).  Single-wave workgroup per (tile, stream).
+//
+// The recurrence runs backwards over the symbols with two interleaved states; even lanes carry state0, odd lanes
+// state1 (lanes 2..63 replicate lanes 0/1, so nothing in the loop needs a lane mask except the stores).  The
+// dependent chain per step is kept short:
+//   * hot-symbol cache: the two most probable symbols' (cum, F) live in registers; a step whose slot falls into one of
+//     them needs no table lookup at all (alpha and nl streams are heavily skewed).  Otherwise slot -> symbol comes
+//     from an LDS byte table and (F, cum) from a 256-entry LDS table;
+//   * renormalisation words: the cursor is a SCALAR (it moves by popcount of a 2-bit ballot; state1 pops first as in
+//     libxpng.c:486-487); words are staged coalesced into an LDS ring and the two candidates words[rw-1], words[rw-2]
+//     are read speculatively at the top of the step, off the dependent chain;
+//   * decoded symbols go to an LDS ring and are flushed 512 at a time.
+// MAXPB bounds the slot table (2^MAXPB bytes of LDS): 12 for the nl-context streams, 15 for alpha.  A block whose
+// header asks for more than MAXPB is left to the general (MAXPB = 15) launch (`only_over` selects those).
+template <int MAXPB>
+__global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__ info,
+                                                     const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first,
+                                                     uint32_t c_count, int only_over, uint8_t *__restrict__ ctxsym,
+                                                     uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg) {
+    __shared__ uint8_t slot2sym[1 << MAXPB];
     __shared__ uint32_t fc[256];
     __shared__ uint32_t Fs[260];
-    const uint32_t j = blockIdx.x / spt, c = blockIdx.x % spt, lane = threadIdx.x & 63;
+    __shared__ uint32_t wring[512];
+    __shared__ uint8_t oring[512];
+    const uint32_t j = blockIdx.x / c_count, c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63, par = lane & 1;
     const DecTile d = info[j];
     if (d.type == 0) return;
-    const TileDesc t = tiles[t0 + j];
-    const uint8_t *in = blobs + d.off + d.blk_off[c];
+    const uint32_t vt = vtile(sel, j);
+    const TileDesc t = tiles[vt];
+    const uint8_t *in = d.blob + d.blk_off[c];
     uint8_t *out = c < 9 ? ctxsym + t.pbase + d.ctx_start[c] : asym + t.pbase;
-    const uint32_t h0 = ld32u(in), type = h0 >> 24;
-    if (type == 0) return;
+    const uint32_t h0 = sgpr(ld32u(in)), type = h0 >> 24;  // header words are wave-uniform: keep them (and every loop
+    if (type == 0) return;                                  // cursor derived from them) in SGPRs
     const uint32_t csz = h0 & 0xFFFFFF;
     const uint8_t *end = in + csz;
-    const uint32_t h1 = ld32u(in + 4), n = h1 & 0xFFFFFF, v2 = h1 >> 24;
+    const uint32_t h1 = sgpr(ld32u(in + 4)), n = h1 & 0xFFFFFF, v2 = h1 >> 24;
+    if (type <= 2 && only_over) return;
     if (type == 1) {  // one distinct symbol
         for (uint32_t i = lane; i < n; i += 64) out[i] = (uint8_t)v2;
         return;
@@ -128,8 +154,12 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const uint8_t *__restrict__
         return;
     }
     const uint32_t N = v2 + 2;
-    const uint32_t h2 = ld32u(in + 8);
+    const uint32_t h2 = sgpr(ld32u(in + 8));
     const int pb = (int)(h2 >> 24);
+    if ((pb > MAXPB) || (only_over && pb <= 12)) return;  // handled by the other launch
+    uint64_t *stamp = dbg ? dbg + ((uint64_t)vt * 10 + c) * 8 : nullptr;
+#define XPNG_DSTAMP(k) do { if (stamp && lane == 0) stamp[k] = __builtin_readcyclecounter(); } while (0)
+    XPNG_DSTAMP(0);
     const uint8_t *words = in + 12;
     const uint8_t *table = in + 8 + 4ull * (h2 & 0xFFFFFF);
     if (lane == 0) {  // frequency table: <= 256 short fields, serial bit reader
@@ -142,6 +172,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const uint8_t *__restrict__
         }
     }
     __syncthreads();
+    uint32_t hot0, hot1;  // (F << 8 | sym) of the two most probable symbols
     {   // cum by 4-per-lane partial sums + wave scan; fc[i] = F | cum << 16
         const uint32_t b = lane * 4;
         const uint32_t f0 = b + 0 < N ? Fs[b + 0] : 0, f1 = b + 1 < N ? Fs[b + 1] : 0, f2 = b + 2 < N ? Fs[b + 2] : 0, f3 = b + 3 < N ? Fs[b + 3] : 0;
@@ -157,79 +188,129 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const uint8_t *__restrict__
         if (b + 1 < N) fc[b + 1] = f1 | (c1 << 16);
         if (b + 2 < N) fc[b + 2] = f2 | (c2 << 16);
         if (b + 3 < N) fc[b + 3] = f3 | (c3 << 16);
+        auto wmax = [&](uint32_t v) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(v, off); v = o > v ? o : v; }
+            return v;
+        };
+        const uint32_t k0 = (f0 << 8) | (b + 0), k1 = (f1 << 8) | (b + 1), k2 = (f2 << 8) | (b + 2), k3 = (f3 << 8) | (b + 3);
+        uint32_t m = k0 > k1 ? k0 : k1; m = k2 > m ? k2 : m; m = k3 > m ? k3 : m;
+        hot0 = wmax(m);
+        auto ex = [&](uint32_t k) { return k == hot0 ? 0u : k; };
+        uint32_t m2 = ex(k0) > ex(k1) ? ex(k0) : ex(k1); m2 = ex(k2) > m2 ? ex(k2) : m2; m2 = ex(k3) > m2 ? ex(k3) : m2;
+        hot1 = wmax(m2);
     }
     __syncthreads();
     {   // slot -> symbol: every lane fills slots by binary search over cum (N <= 256 -> 8 probes)
         const uint32_t scale = 1u << pb;
         for (uint32_t s = lane; s < scale; s += 64) {
-            uint32_t lo = 0, hi = N - 1;  // largest i with cum[i] <= s and F[i] > 0 region containing s
+            uint32_t lo = 0, hi = N - 1;  // largest index with cum <= s
             while (lo < hi) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
                 if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
             }
-            // symbols with F == 0 share their cum with the next used one: step down to the one that owns the slot
-            // (the used symbol is the LAST index among equal cums whose F > 0 ... the search above lands on the
-            // largest index with cum <= s; zero-width followers have cum == next cum > s only if they sit after)
-            while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;
+            while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
             slot2sym[s] = (uint8_t)lo;
         }
     }
     __syncthreads();
-    // ---- the recurrence, backwards (libxpng.c:467-489).  lane 0 = state0, lane 1 = state1.
+    XPNG_DSTAMP(1);
+    const uint32_t sym0 = hot0 & 255u, sym1 = hot1 & 255u;
+    const uint32_t e0 = fc[sym0], e1 = fc[sym1];
+    const uint32_t F0 = e0 & 0xFFFF, C0 = e0 >> 16, F1 = (hot1 >> 8) ? (e1 & 0xFFFF) : 0u, C1 = e1 >> 16;
     const uint32_t mask = (1u << pb) - 1;
     const uint8_t *sp = table - 16;  // state0 at table-16, state1 at table-8
-    uint64_t s = lane < 2 ? ld64u(sp + 8 * lane) : RANS_L;
-    int32_t rw = (int32_t)((sp - words) >> 2);  // words still unread below the states; both lanes track it
-    int64_t i = (int64_t)n;
-    if (n & 1) {  // odd tail comes from state0 only
-        i--;
-        if (lane == 0) {
-            const uint32_t slot = (uint32_t)s & mask, sym = slot2sym[slot], e = fc[sym];
-            out[i] = (uint8_t)sym;
-            s = (uint64_t)(e & 0xFFFF) * (s >> pb) + slot - (e >> 16);
+    const uint32_t nw = (uint32_t)((sp - words) >> 2);  // renormalisation words below the states
+    uint32_t rw = nw;                                    // scalar cursor: next word to pop is words[rw-1]
+    uint32_t ring_lo = nw > 512 ? nw - 512 : 0;          // ring holds word indices [ring_lo, ring_lo + 512)
+    for (uint32_t i = ring_lo + lane; i < nw; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
+    uint64_t s = ld64u(sp + 8 * par);
+    __syncthreads();
+    auto refill = [&]() {  // uniform: bring the next lower 256 words into the ring before the cursor reaches them
+        if (ring_lo > 0 && rw < ring_lo + 128) {
+            const uint32_t new_lo = ring_lo > 256 ? ring_lo - 256 : 0;
+            __syncthreads();
+            for (uint32_t i = new_lo + lane; i < ring_lo; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
+            ring_lo = new_lo;
+            __syncthreads();
         }
-        const uint32_t need0 = __shfl((lane == 0 && s < RANS_L) ? 1u : 0u, 0);
+    };
+    auto flush = [&](uint32_t base) {  // uniform: symbols [base, min(base+512, n)) leave the LDS ring
+        __syncthreads();
+        const uint32_t hi = base + 512 < n ? base + 512 : n;
+        for (uint32_t i = base + lane; i < hi; i += 64) out[i] = oring[i & 511u];
+        __syncthreads();
+    };
+    auto decode_one = [&](uint32_t &sym) {  // one symbol out of this lane's state; returns whether it must refill
+        const uint32_t slot = (uint32_t)s & mask;
+        const uint32_t d0 = slot - C0, d1 = slot - C1;
+        const bool hit0 = d0 < F0, hit1 = d1 < F1;
+        uint32_t F, off;
+        if (__ballot(!(hit0 || hit1)) == 0) {
+            F = hit0 ? F0 : F1; off = hit0 ? d0 : d1; sym = hit0 ? sym0 : sym1;
+        } else {
+            sym = slot2sym[slot];
+            const uint32_t e = fc[sym];
+            F = e & 0xFFFF; off = slot - (e >> 16);
+        }
+        s = (uint64_t)F * (s >> pb) + off;
+        return s < RANS_L;
+    };
+    rw = sgpr(rw); ring_lo = sgpr(ring_lo);
+    uint32_t i = sgpr(n);  // scalar
+    if (n & 1) {  // odd tail comes from state0 only (libxpng.c:471-476)
+        i--;
+        uint32_t sym = 0;
+        const uint64_t keep = s;
+        const bool need = decode_one(sym);
+        if (par) s = keep;
+        const uint32_t need0 = sgpr((uint32_t)__ballot(need && !par) & 1u);
         if (need0) {
             if (rw > 0) rw--;
-            if (lane == 0) s = (s << 32) | ld32u(words + 4 * (int64_t)rw);
+            if (!par) s = (s << 32) | wring[rw & 511u];
         }
+        if (lane == 0) oring[i & 511u] = (uint8_t)sym;
+        if ((i & 511u) == 0) flush(i);
     }
-    for (i -= 2; i >= 0; i -= 2) {
-        // speculative reads of the next two words (addresses depend only on rw, not on this step's states)
-        const int32_t r1 = rw > 0 ? rw - 1 : 0, r2 = rw > 1 ? rw - 2 : 0;
-        const uint32_t w1 = ld32u(words + 4 * (int64_t)r1), w2 = ld32u(words + 4 * (int64_t)r2);
-        uint32_t need = 0;
-        if (lane < 2) {
-            const uint32_t slot = (uint32_t)s & mask, sym = slot2sym[slot], e = fc[sym];
-            out[i + lane] = (uint8_t)sym;
-            s = (uint64_t)(e & 0xFFFF) * (s >> pb) + slot - (e >> 16);
-            need = s < RANS_L ? 1u : 0u;
+    // The two candidate words words[rw-1], words[rw-2] live in registers and are re-read from the LDS ring only in the
+    // (wave-uniform) steps that actually consumed one: skewed streams renormalise once per tens of steps, so most steps
+    // issue no LDS word read at all.  Decoded symbols are packed 4 steps deep per lane before they touch the LDS ring.
+    uint32_t w1 = wring[(rw > 0 ? rw - 1 : 0) & 511u], w2 = wring[(rw > 1 ? rw - 2 : 0) & 511u];
+    while (i >= 2) {
+        i -= 2;
+        uint32_t sym = 0;
+        const bool need = decode_one(sym);
+        const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
+        if (lane < 2) oring[(i + par) & 511u] = (uint8_t)sym;
+        if (m) {  // uniform, rare: state1 refills first (libxpng.c:486-487)
+            const uint32_t n1 = m >> 1, n0 = m & 1u;
+            if (need) s = (s << 32) | (par ? w1 : (n1 ? w2 : w1));
+            rw = rw > n0 + n1 ? rw - (n0 + n1) : 0;
+            refill();
+            w1 = wring[(rw > 0 ? rw - 1 : 0) & 511u];
+            w2 = wring[(rw > 1 ? rw - 2 : 0) & 511u];
         }
-        const uint32_t other = swap_pair(need);
-        // state1 refills first (libxpng.c:486-487)
-        if (lane == 1 && need) s = (s << 32) | w1;
-        if (lane == 0 && need) s = (s << 32) | (other ? w2 : w1);
-        rw -= (int32_t)(need + other);
-        if (rw < 0) rw = 0;
+        if ((i & 511u) == 0) flush(i);
     }
+    XPNG_DSTAMP(2);
 }
 
 // --------------------------------------------------------------------------------------------------
 // alpha plane (RGBA).  a(x,y) = a(left) + d, except column 0: a(0,y) = a(0,y-1) + d (libxpng.c:798-800 with
 // pr = p1x_ for rows 0 / interior and p1y_ for column 0).  grid = tiles, block = 1024.
-__global__ __launch_bounds__(1024) void k_dec_alpha(const uint8_t *__restrict__ blobs, const DecTile *__restrict__ info,
-                                                    const TileDesc *__restrict__ tiles, uint32_t t0,
+__global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ info,
+                                                    const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ asym, uint8_t *__restrict__ alpha) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DecTile d = info[j];
     if (d.type == 0) return;
-    const TileDesc t = tiles[t0 + j];
+    const TileDesc t = tiles[vtile(sel, j)];
     const uint8_t *sy = asym + t.pbase;  // sy[i-1] = symbol of pixel i
     uint8_t *al = alpha + t.pbase;
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     // first pixel's alpha: 4th byte of the first k word (MSB-first R,G,B,A)
-    const uint32_t a0 = ld32u(blobs + d.off + 8) & 0xFF;
+    const uint32_t a0 = ld32u(d.blob + 8) & 0xFF;
     // ---- column 0: inclusive scan down the rows
     if (tid == 0) s_carry = a0;
     __syncthreads();
@@ -272,48 +353,82 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const uint8_t *__restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------------
-// context chain (libxpng.c:803: nl = *cx[nl]++, starting from 0).  One wave per tile; lane c < 9 owns queue c:
-// an 8-symbol register window plus one prefetched 8-byte chunk.  Each step: broadcast the head of the current
-// queue with v_readlane, pop it on the owning lane.  Output: nl sequence in coded-pixel order.
+// context chain (libxpng.c:803: nl = *cx[nl]++, starting from 0).  Strictly serial per tile, so one wave per tile and
+// the step is made as short as the hardware allows: lane c < 9 owns queue c as an 8-symbol register window (low byte =
+// head) backed by two prefetched 8-byte chunks; a step is v_readlane (head of the current queue -> SGPR), a predicated
+// 8-bit shift on the owning lane, and a scalar pack of the output.  No LDS, no global load on the dependent chain.
+// Output: nl sequence in coded-pixel order.      grid = tiles, block = 64.
 __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
-                                                 uint32_t t0, const uint8_t *__restrict__ ctxsym,
+                                                 TileSel sel, const uint8_t *__restrict__ ctxsym,
                                                  uint8_t *__restrict__ nlseq) {
     const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
     const DecTile d = info[j];
     if (d.type == 0) return;
-    const TileDesc t = tiles[t0 + j];
-    const uint32_t total = d.ctx_start[9];
-    const uint8_t *base = ctxsym + t.pbase;
+    const TileDesc t = tiles[vtile(sel, j)];
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ctx_start[9]);
+    const uint8_t *base = ctxsym + t.pbase;  // 256-byte aligned, padded: chunk loads never leave the plane
     uint8_t *out = nlseq + t.pbase;
-    // per-lane queue state (lanes >= 9 idle)
+    // queue supply: every queue is staged through its own 2 KB LDS ring in 1 KB units (coalesced copies by the whole
+    // wave, triggered at 8-step block boundaries when a queue's read position nears the end of what is staged).
+    __shared__ __align__(16) uint8_t qring[9][2048];
     const uint32_t qs = lane < 9 ? d.ctx_start[lane] : 0;
-    uint64_t rd = qs;              // next byte index to load into the prefetch chunk
-    uint64_t win = 0, nxt = 0;     // current window (low byte = head), prefetched chunk
-    uint32_t have = 0, nhave = 0;  // valid bytes in win / nxt
-    auto load_chunk = [&](uint64_t &dst, uint32_t &cnt) {  // up to 8 bytes starting at base[rd], byte-wise (unaligned queue starts)
-        const uint64_t a = rd & ~7ull;
-        const uint64_t raw = *reinterpret_cast<const uint64_t *>(base + a);  // planes are 256-B padded: always in bounds
-        const uint32_t skip = (uint32_t)(rd - a);
-        dst = raw >> (8 * skip);
-        cnt = 8 - skip;
-        rd = a + 8;
-    };
-    if (lane < 9) { load_chunk(win, have); load_chunk(nxt, nhave); }
+    const uint32_t qsa = qs & ~15u;  // 16-byte aligned start of this lane's queue inside the tile's symbol area
+    for (uint32_t c = 0; c < 9; c++) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, (int)c);
+        const uint4 *src = reinterpret_cast<const uint4 *>(base + a) + lane;
+        reinterpret_cast<uint4 *>(qring[c])[lane] = src[0];
+        reinterpret_cast<uint4 *>(qring[c])[64 + lane] = src[64];
+    }
+    __syncthreads();
+    uint32_t filled = 2;                      // units staged for this lane's queue
+    const uint32_t p0 = qs & 15u;             // ring position of the queue's first symbol
+    const uint32_t ql = lane < 9 ? lane : 0;  // lanes >= 9 never pop; they alias queue 0 harmlessly
+    uint64_t win = *reinterpret_cast<const uint64_t *>(&qring[ql][p0 & ~7u]) >> (8 * (p0 & 7u));
+    uint32_t have = 8 - (p0 & 7u);
+    uint32_t rdpos = (p0 & ~7u) + 8;          // next ring position to load into the register window
     uint32_t cur = 0;
-    uint64_t packed = 0;  // 8 output symbols staged before one 8-byte store
-    for (uint32_t k = 0; k < total; k++) {
-        const uint32_t head = (uint32_t)win & 0xFF;
-        const uint32_t sym = __builtin_amdgcn_readlane((int)head, (int)cur);
-        if (lane == cur) {
-            win >>= 8;
-            if (--have == 0) { win = nxt; have = nhave; load_chunk(nxt, nhave); }
+    auto restage = [&]() {  // uniform entry; copies one more unit for every queue that is within 32 bytes of its staged end
+        uint64_t m = __ballot(lane < 9 && rdpos + 32 >= filled * 1024u);
+        if (m == 0) return;
+        __syncthreads();
+        while (m) {
+            const int c = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, c);
+            const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)filled, c);
+            const uint4 v = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * 64];
+            reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * 64 + lane] = v;
+            if ((int)lane == c) filled++;
+        }
+        __syncthreads();
+    };
+    auto pop = [&]() -> uint32_t {  // returns the next nl (wave-uniform) and advances the owning queue
+        const uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)win, (int)cur) & 0xFFu;
+        const bool mine = lane == cur;
+        win >>= mine ? 8 : 0;
+        have -= mine ? 1u : 0u;
+        if (have == 0) {  // divergent, once per 8 pops of a queue: next 8 symbols from the LDS ring
+            win = *reinterpret_cast<const uint64_t *>(&qring[ql][rdpos & 2047u]);
+            rdpos += 8;
+            have = 8;
         }
         cur = sym;
-        packed |= (uint64_t)sym << (8 * (k & 7));
-        if ((k & 7) == 7) { if (lane == 0) *reinterpret_cast<uint64_t *>(out + (k & ~7u)) = packed; packed = 0; }
+        return sym;
+    };
+    uint32_t k = 0;
+    for (; k + 8 <= total; k += 8) {
+        restage();
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) lo |= pop() << (8 * u);
+#pragma unroll
+        for (int u = 0; u < 4; u++) hi |= pop() << (8 * u);
+        if (lane == 0) *reinterpret_cast<uint2 *>(out + k) = make_uint2(lo, hi);
     }
-    if ((total & 7) && lane == 0) {
-        for (uint32_t r = 0; r < (total & 7); r++) out[(total & ~7u) + r] = (uint8_t)(packed >> (8 * r));
+    restage();
+    for (; k < total; k++) {
+        const uint32_t sy = pop();
+        if (lane == 0) out[k] = (uint8_t)sy;
     }
 }
 
@@ -322,15 +437,15 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 // coded index = running count, bit cursor = running sum of 3*nl; pulls 3*nl bits out of k, undoes zig-zag
 // and the green subtraction, and stores one packed word per pixel: r | g<<8 | b<<16 | coded<<24.
 template <int PXSZ>
-__global__ __launch_bounds__(1024) void k_dec_resid(const uint8_t *__restrict__ blobs, const DecTile *__restrict__ info,
-                                                    const TileDesc *__restrict__ tiles, uint32_t t0,
+__global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ info,
+                                                    const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint8_t *__restrict__ nlseq,
                                                     uint32_t *__restrict__ resid) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DecTile d = info[j];
     if (d.type == 0) return;
-    const TileDesc t = tiles[t0 + j];
-    const uint8_t *kbase = blobs + d.off + 8, *kend = kbase + d.kbytes;
+    const TileDesc t = tiles[vtile(sel, j)];
+    const uint8_t *kbase = d.blob + 8, *kend = kbase + d.kbytes;
     const uint8_t *al = alpha + t.pbase, *nls = nlseq + t.pbase;
     uint32_t *rs = resid + t.pbase;
     const int useG = d.type & 1;
@@ -388,16 +503,16 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const uint8_t *__restrict__ 
 // thread r-1 produced one step earlier (LDS, double-buffered by step parity), its UL is its previous U, its L its own
 // previous output.  Tiles taller than 1024 rows run in bands; a band's first row reads U from the raster.
 template <int PXSZ>
-__global__ __launch_bounds__(1024) void k_dec_recon(const uint8_t *__restrict__ blobs, const DecTile *__restrict__ info,
-                                                    const TileDesc *__restrict__ tiles, uint32_t t0,
+__global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ info,
+                                                    const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint32_t *__restrict__ resid,
-                                                    uint8_t *__restrict__ raster, uint64_t bpr) {
+                                                    uint8_t *const *__restrict__ rasters, uint64_t bpr) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x;
     const DecTile d = info[j];
-    const TileDesc t = tiles[t0 + j];
-    uint8_t *dst = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
+    const TileDesc t = tiles[vtile(sel, j)];
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
     if (d.type == 0) {
-        const uint8_t *src = blobs + d.off + 4;
+        const uint8_t *src = d.blob + 4;
         const uint64_t row = (uint64_t)t.w * PXSZ;
         for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
         return;
@@ -407,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const uint8_t *__restrict__ 
     const uint32_t *rs = resid + t.pbase;
     __shared__ uint32_t s_row[2][1024];
     // first pixel from the head of k (libxpng.c:850): bytes MSB-first
-    const uint32_t kw0 = ld32u(blobs + d.off + 8);
+    const uint32_t kw0 = ld32u(d.blob + 8);
     uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16);
     if (PXSZ == 4) first |= (kw0 & 255u) << 24;
     for (uint32_t yb = 0; yb < t.h; yb += 1024) {
@@ -465,34 +580,57 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const uint8_t *__restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------------
-inline int decode_m1_launch(DecodeWs &ws, const std::vector<TileDesc> &tiles, const TileDesc *d_tiles, uint64_t W, int pxsz,
-                            const uint8_t *d_blobs, uint64_t blobs_len, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
-                            uint8_t *d_raster, hipStream_t s, std::string &err) {
-    const uint32_t cnt = t1 - t0, spt = pxsz == 4 ? 10 : 9;
-    const uint64_t plane = tiles.back().pbase + rup(tiles.back().n + 8, 256);
+// Launch the whole decode of tiles [t0, t1) of every image of the batch.  d_blob_ptrs / d_raster_ptrs are device arrays
+// of B pointers; tile_off holds B * cnt blob offsets (image-major), relative to each image's blob buffer.
+inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
+                            int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
+                            uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr) {
+    const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
+    const TileSel sel{t0, cnt, (uint32_t)n_tiles};
+    const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
-    if (ws.cap_tiles < tiles.size() || ws.cap_plane < plane) {
+    if (ws.cap_tiles < (uint64_t)B * n_tiles || ws.cap_plane < plane) {
         decode_ws_free(ws);
-        if (hipMalloc((void **)&ws.d_info, tiles.size() * sizeof(DecTile)) != hipSuccess || hipMalloc((void **)&ws.d_off, tiles.size() * 8) != hipSuccess ||
-            hipMalloc((void **)&ws.d_ctxsym, plane + 64) != hipSuccess || hipMalloc((void **)&ws.d_asym, plane + 64) != hipSuccess ||
+        if (hipMalloc((void **)&ws.d_info, (uint64_t)B * n_tiles * sizeof(DecTile)) != hipSuccess || hipMalloc((void **)&ws.d_off, (uint64_t)B * n_tiles * 8) != hipSuccess ||
+            hipMalloc((void **)&ws.d_ctxsym, plane + 8192) != hipSuccess || hipMalloc((void **)&ws.d_asym, plane + 64) != hipSuccess ||
             hipMalloc((void **)&ws.d_alpha, plane + 64) != hipSuccess || hipMalloc((void **)&ws.d_nlseq, plane + 64) != hipSuccess ||
             hipMalloc((void **)&ws.d_resid, 4 * plane + 64) != hipSuccess)
             return bad("hipMalloc failed (decode workspace)");
-        ws.cap_tiles = tiles.size(); ws.cap_plane = plane;
+        ws.cap_tiles = (uint64_t)B * n_tiles; ws.cap_plane = plane;
     }
-    (void)blobs_len;
-    if (hipMemcpyAsync(ws.d_off, tile_off, (uint64_t)cnt * 8, hipMemcpyHostToDevice, s) != hipSuccess) return bad("tile offset upload failed");
+    if (ws.last_off.size() != total || ws.last_t0 != t0 || memcmp(ws.last_off.data(), tile_off, (size_t)total * 8) != 0) {
+        // pageable host memory: the copy is staged synchronously, so only pay for it when the offsets changed
+        if (hipMemcpyAsync(ws.d_off, tile_off, (uint64_t)total * 8, hipMemcpyHostToDevice, s) != hipSuccess) return bad("tile offset upload failed");
+        if (hipStreamSynchronize(s) != hipSuccess) return bad("tile offset upload failed");
+        ws.last_off.assign(tile_off, tile_off + total);
+        ws.last_t0 = t0;
+    }
     const uint64_t bpr = W * (uint64_t)pxsz;
-    k_dec_parse<<<(cnt + 63) / 64, 64, 0, s>>>(d_blobs, ws.d_off, cnt, spt, ws.d_info);
-    k_rans2_decode<<<cnt * spt, 64, 0, s>>>(d_blobs, ws.d_info, d_tiles, t0, spt, ws.d_ctxsym, ws.d_asym);
-    if (pxsz == 4) k_dec_alpha<<<cnt, 1024, 0, s>>>(d_blobs, ws.d_info, d_tiles, t0, ws.d_asym, ws.d_alpha);
-    k_dec_walk<<<cnt, 64, 0, s>>>(ws.d_info, d_tiles, t0, ws.d_ctxsym, ws.d_nlseq);
+    if (!ws.side) {
+        if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess)
+            return bad("stream/event creation failed");
+    }
+    k_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, cnt, total, spt, ws.d_info);
+    // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short
+    // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
-        k_dec_resid<4><<<cnt, 1024, 0, s>>>(d_blobs, ws.d_info, d_tiles, t0, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        k_dec_recon<4><<<cnt, 1024, 0, s>>>(d_blobs, ws.d_info, d_tiles, t0, ws.d_alpha, ws.d_resid, d_raster, bpr);
+        if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
+        k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
+        k_dec_alpha<<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
+        if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
+    }
+    k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
+    k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
+    k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
+    if (pxsz == 4) {
+        if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
+        k_dec_resid<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
+        k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr);
     } else {
-        k_dec_resid<3><<<cnt, 1024, 0, s>>>(d_blobs, ws.d_info, d_tiles, t0, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        k_dec_recon<3><<<cnt, 1024, 0, s>>>(d_blobs, ws.d_info, d_tiles, t0, ws.d_alpha, ws.d_resid, d_raster, bpr);
+        k_dec_resid<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
+        k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr);
     }
     if (hipGetLastError() != hipSuccess) return bad("decode kernel launch failed");
     return 0;

@@ -19,11 +19,12 @@ namespace xpng {
 // y%4==3) is costed under avg / avg+G / grad / grad+G; the four sums go to sums[tile*4..] by atomics.
 // grid = tiles * strips, block = 256.
 template <int PXSZ>
-__global__ __launch_bounds__(256) void k_chooser(const uint8_t *__restrict__ raster, uint64_t bpr,
-                                                 const TileDesc *__restrict__ tiles, uint32_t t0, uint32_t strips,
+__global__ __launch_bounds__(256) void k_chooser(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                 const TileDesc *__restrict__ tiles, TileSel sel, uint32_t strips,
                                                  uint32_t *__restrict__ sums) {
-    const uint32_t tile = t0 + blockIdx.x / strips, strip = blockIdx.x % strips;
+    const uint32_t tile = vtile(sel, blockIdx.x / strips), strip = blockIdx.x % strips;
     const TileDesc t = tiles[tile];
+    const uint8_t *__restrict__ raster = rasters[t.img];
     if (t.w < 4 || t.h < 4) return;
     const uint32_t xs = t.w >> 2, ys = t.h >> 2;
     const uint32_t j0 = (uint32_t)((uint64_t)ys * strip / strips), j1 = (uint32_t)((uint64_t)ys * (strip + 1) / strips);
@@ -99,12 +100,13 @@ __device__ __forceinline__ void m1_pixel(uint32_t cur, uint32_t L, uint32_t U, u
 // below takes over for ordinary tiles.
 // grid = tiles * blocks_per_tile, block = 256 (1024 pixels per block).
 template <int PXSZ>
-__global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *__restrict__ raster, uint64_t bpr,
-                                                              const TileDesc *__restrict__ tiles, uint32_t t0,
+__global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                              const TileDesc *__restrict__ tiles, TileSel sel,
                                                               uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
                                                               uint8_t *__restrict__ planes, uint64_t plane_stride) {
-    const uint32_t tile = t0 + blockIdx.x / blocks_per_tile, chunk = blockIdx.x % blocks_per_tile;
+    const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
     const TileDesc t = tiles[tile];
+    const uint8_t *__restrict__ raster = rasters[t.img];
     const uint32_t i0 = (chunk * 256 + threadIdx.x) * 4;
     if (i0 >= t.n) return;
     const int pr = pr_from_sums(sums + (uint64_t)tile * 4, PXSZ, t.w, t.h);
@@ -147,13 +149,14 @@ constexpr int ST_THREADS = 1024, ST_WAVES = ST_THREADS / 64;
 constexpr int ST_WORDS = ST_THREADS * 24 / 32 + 4;
 
 template <int PXSZ>
-__global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *__restrict__ raster, uint64_t bpr,
-                                                           const TileDesc *__restrict__ tiles, uint32_t t0,
+__global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                           const TileDesc *__restrict__ tiles, TileSel sel,
                                                            const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                            uint8_t *__restrict__ scratch, uint32_t *__restrict__ ctx_n,
                                                            uint32_t *__restrict__ k_n) {
-    const uint32_t tile = t0 + blockIdx.x;
+    const uint32_t tile = vtile(sel, blockIdx.x);
     const TileDesc t = tiles[tile];
+    const uint8_t *__restrict__ raster = rasters[t.img];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint8_t *pnl = planes + t.pbase, *pr_ = planes + plane_stride + t.pbase;
     const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;

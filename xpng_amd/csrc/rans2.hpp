@@ -52,18 +52,45 @@ struct BitW {
 // (uniform across the wave).  Must be called by all 64 lanes of a single-wave workgroup.
 // LDS: hist[256], cum[257], tab[256].
 __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, uint32_t n, uint32_t nominalN, int pb,
-                                              uint8_t *__restrict__ out8, uint32_t *hist, uint32_t *cum, EncSym *tab) {
+                                              uint8_t *__restrict__ out8, uint32_t *hist, uint32_t *cum, EncSym *tab,
+                                              uint64_t *stamp = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *out = reinterpret_cast<uint32_t *>(out8);
     if (n == 0) {  // libxpng.c:313
         if (lane == 0) out[0] = 4;
         return 4;
     }
-    // ---- histogram (the reference counts F[] while routing; same numbers)
-    for (uint32_t i = lane; i < 256; i += 64) hist[i] = 0;
+#define XPNG_STAMP(k) do { if (stamp && lane == 0) stamp[k] = __builtin_readcyclecounter(); } while (0)
+    XPNG_STAMP(0);
+    // ---- histogram (the reference counts F[] while routing; same numbers).  16 symbols per lane per load; four
+    // sub-histograms (lane & 3) cut the same-address LDS atomic serialisation of skewed streams.
+    __shared__ uint32_t hsub[4][256];
+    for (uint32_t i = lane; i < 1024; i += 64) (&hsub[0][0])[i] = 0;
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) atomicAdd(&hist[in[i]], 1u);
+    {
+        uint32_t *hs = hsub[lane & 3];
+        const uint32_t head = (uint32_t)((16 - ((uintptr_t)in & 15)) & 15);
+        const uint32_t nh = head < n ? head : n;
+        if (lane < nh) atomicAdd(&hs[in[lane]], 1u);
+        const uint32_t vecs = (n - nh) >> 4;
+        const uint4 *v = reinterpret_cast<const uint4 *>(in + nh);
+        for (uint32_t i = lane; i < vecs; i += 64) {
+            const uint4 q = v[i];
+            const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&hs[w4[k] & 255u], 1u);
+                atomicAdd(&hs[(w4[k] >> 8) & 255u], 1u);
+                atomicAdd(&hs[(w4[k] >> 16) & 255u], 1u);
+                atomicAdd(&hs[w4[k] >> 24], 1u);
+            }
+        }
+        for (uint32_t i = nh + (vecs << 4) + lane; i < n; i += 64) atomicAdd(&hs[in[i]], 1u);
+    }
     __syncthreads();
+    for (uint32_t i = lane; i < 256; i += 64) hist[i] = hsub[0][i] + hsub[1][i] + hsub[2][i] + hsub[3][i];
+    __syncthreads();
+    XPNG_STAMP(1);
     // ---- alphabet: N = 1 + highest used symbol, distinct count (libxpng.c:314-317)
     uint32_t top = 0, distinct = 0;
     for (uint32_t i = lane; i < nominalN; i += 64) {
@@ -137,42 +164,98 @@ __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, ui
     for (uint32_t i = lane; i < N; i += 64) hist[i] = cum[i + 1] - cum[i];  // hist := normalised F
     __syncthreads();
 
-    // ---- the recurrence (libxpng.c:362-392).  Lane 0 = state0 / even symbols, lane 1 = state1 / odd.
+    XPNG_STAMP(2);
+    // ---- the recurrence (libxpng.c:362-392).  Even lanes run state0 (even symbols), odd lanes state1 (odd
+    // symbols); lanes 2..63 replicate lanes 0/1 so the loop has no per-lane validity masks (they never write).
+    //  * symbols: each lane walks its own stride-2 byte sequence through a 64-bit register window (4 symbols)
+    //    backed by two prefetched 8-byte chunks, so no global-load latency sits in the loop;
+    //  * table entries: fetched three steps ahead of the state update (rotating registers), so the LDS latency is
+    //    off the dependent chain, which is only: spill test -> 64x64 mulhi -> shift -> mad;
+    //  * spilled words: positions come from a 2-bit ballot (state0's word before state1's, as the reference emits
+    //    them), so the cursor is a scalar; words are staged in an LDS ring and flushed 256 at a time, coalesced.
     uint32_t *w = out + 3;
-    uint64_t s = RANS_L;
-    uint32_t cnt = 0;
+    __shared__ uint32_t ring[512];
+    const uint32_t par = lane & 1;
     const uint32_t cmpl_base = 1u << pb;
     const int thr_shift = 31 - pb;
-    const uint32_t steps = (n + 1) >> 1;
-    // Symbols and table entries do not depend on the state, so a block of 8 steps is fetched up front
-    // (8 byte loads + 8 ds_read_b128 in flight) and only the 64-bit recurrence stays serial.
-    for (uint32_t k0 = 0; k0 < steps; k0 += 8) {
-        EncSym e[8];
-        bool valid[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t idx = 2 * (k0 + u) + lane;
-            valid[u] = lane < 2 && idx < n;
-            e[u] = tab[valid[u] ? in[idx] : in[0]];
+    uint64_t s = RANS_L;
+    uint32_t cnt = 0, flushed = 0;  // wave-uniform
+    {
+        // symbol supply: the stream is staged through a 2 KB LDS ring in 1 KB units, copied coalesced by the whole
+        // wave; the unit after the newest one sits prefetched in registers (one 16-byte load per lane in flight).
+        __shared__ __align__(16) uint8_t sring[2048];
+        const uint8_t *inA = reinterpret_cast<const uint8_t *>((uintptr_t)in & ~(uintptr_t)15);
+        const uint32_t p0 = (uint32_t)((uintptr_t)in & 15);  // ring position of symbol 0
+        const uint4 *src = reinterpret_cast<const uint4 *>(inA) + lane;
+        reinterpret_cast<uint4 *>(sring)[lane] = src[0];
+        reinterpret_cast<uint4 *>(sring)[64 + lane] = src[64];
+        uint4 pre = src[128];
+        uint32_t filled = 2;        // units already in the ring (uniform)
+        uint32_t pos = sgpr(p0);    // ring position of the next symbol PAIR to hand out (uniform)
+        __syncthreads();
+        auto next_sym = [&]() -> uint32_t {
+            if (pos + 8 >= filled * 1024u) {  // uniform: rotate the prefetched unit in, start the next load
+                __syncthreads();
+                reinterpret_cast<uint4 *>(sring)[(filled & 1u) * 64 + lane] = pre;
+                filled++;
+                pre = src[filled * 64];
+                __syncthreads();
+            }
+            const uint32_t sy = sring[(pos + par) & 2047u];
+            pos += 2;
+            return sy;
+        };
+        auto step = [&](const EncSym &e) {
+            const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
+            const bool emit = (uint32_t)(s >> 32) >= (freq << thr_shift);
+            const uint32_t m = sgpr((uint32_t)__ballot(emit) & 3u);  // bit0: state0 spills, bit1: state1 spills
+            const uint32_t e0 = m & 1u;
+            if (emit) {
+                if (lane < 2) ring[(cnt + (par ? e0 : 0u)) & 511u] = (uint32_t)s;
+                s >>= 32;
+            }
+            cnt += e0 + (m >> 1);
+            const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
+            const uint64_t q = __umul64hi(s, rcp) >> rsh;
+            s += e.bias + q * (uint64_t)(cmpl_base - freq);
+            if (cnt - flushed >= 256) {  // uniform
+                __syncthreads();
+                for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
+                flushed += 256;
+                __syncthreads();
+            }
+        };
+        const uint32_t pairs = sgpr(n >> 1);  // steps in which both states code a symbol
+        EncSym ea = tab[next_sym()], eb = tab[next_sym()], ec = tab[next_sym()];
+        uint32_t k = 0;
+        for (; k + 3 <= pairs; k += 3) {
+            step(ea); ea = tab[next_sym()];
+            step(eb); eb = tab[next_sym()];
+            step(ec); ec = tab[next_sym()];
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t freq = e[u].freq_shift & 0xFFFF, rsh = e[u].freq_shift >> 16;
-            const uint32_t emit = (valid[u] && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
-            const uint32_t other = swap_pair(emit);
-            if (emit) { w[cnt + (lane ? other : 0)] = (uint32_t)s; s >>= 32; }
-            cnt += emit + other;
-            if (valid[u]) {
-                const uint64_t rcp = ((uint64_t)e[u].rcp_hi << 32) | e[u].rcp_lo;
+        if (k < pairs) { step(ea); ea = eb; eb = ec; k++; }
+        if (k < pairs) { step(ea); ea = eb; k++; }
+        if (n & 1) {  // odd tail: state0 only (libxpng.c:382-392); odd lanes skip the update
+            const EncSym e = ea;
+            const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
+            const bool emit = par == 0 && (uint32_t)(s >> 32) >= (freq << thr_shift);
+            const uint32_t e0 = sgpr((uint32_t)__ballot(emit) & 1u);
+            if (emit) { if (lane == 0) ring[cnt & 511u] = (uint32_t)s; s >>= 32; }
+            cnt += e0;
+            if (par == 0) {
+                const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
                 const uint64_t q = __umul64hi(s, rcp) >> rsh;
-                s += e[u].bias + q * (uint64_t)(cmpl_base - freq);
+                s += e.bias + q * (uint64_t)(cmpl_base - freq);
             }
         }
+        __syncthreads();
+        for (uint32_t i = flushed + lane; i < cnt; i += 64) w[i] = ring[i & 511u];
     }
-    cnt = __shfl(cnt, 0);
     w += cnt;
     if (lane < 2) { w[2 * lane] = (uint32_t)s; w[2 * lane + 1] = (uint32_t)(s >> 32); }  // state0, state1 (libxpng.c:394)
     w += 4;
+    __syncthreads();
+    XPNG_STAMP(3);
     // ---- header + frequency table (libxpng.c:396-415)
     const uint32_t sparseBits = N + distinct * (uint32_t)pb;
     const bool sparse = sparseBits < N * (uint32_t)pb;
@@ -192,6 +275,7 @@ __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, ui
         out[0] = csz | ((3u + (sparse ? 1u : 0u)) << 24);
     }
     csz = __shfl(csz, 0);
+    XPNG_STAMP(4);
     // ---- raw fallback, type 2 (libxpng.c:417-424): rawBits per symbol, MSB first, parallel over words
     const uint64_t rawTotalBits = (uint64_t)rawBits * n;
     const uint32_t rawWords = (uint32_t)((rawTotalBits + 31) >> 5);
@@ -213,6 +297,7 @@ __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, ui
         csz = 8 + 4 * rawWords;
         if (lane == 0) { out[0] = csz | (2u << 24); out[1] = n | (rawBits << 24); }
     }
+    XPNG_STAMP(5);
     return csz;
 }
 

@@ -12,14 +12,14 @@ namespace xpng {
 // K4  one wavefront per (tile, stream): the entropy stage of enc_1_th (libxpng.c:558-559).
 // Stream c < 9: context stream c, alphabet 9, PROB_BITS 12.  Stream 9 (RGBA): alpha symbols = plane `a`
 // from index 1, alphabet 256, PROB_BITS 15.      grid = tiles * spt, block = 64.
-__global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict__ tiles, uint32_t t0, uint32_t spt,
+__global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                     uint32_t *__restrict__ blk_sz) {
+                                                     uint32_t *__restrict__ blk_sz, uint64_t *__restrict__ dbg) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
-    const uint32_t tile = t0 + blockIdx.x / spt, c = blockIdx.x % spt;
+    const uint32_t tile = vtile(sel, blockIdx.x / spt), c = blockIdx.x % spt;
     const TileDesc t = tiles[tile];
     uint8_t *sc = scratch + t.sbase;
     const uint8_t *in;
@@ -27,18 +27,19 @@ __global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict_
     int pb;
     if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
-    const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, (int)c), hist, cum, tab);
+    const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, (int)c), hist, cum, tab,
+                                           dbg ? dbg + ((uint64_t)tile * 10 + c) * 8 : nullptr);
     if ((threadIdx.x & 63) == 0) blk_sz[(uint64_t)tile * 10 + c] = sz;
 }
 
 // K5a  per-tile size + header word.  One thread per tile.
-__global__ void k_tile_sizes(const TileDesc *__restrict__ tiles, uint32_t t0, uint32_t cnt, int pxsz, uint32_t spt,
+__global__ void k_tile_sizes(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total, int pxsz, uint32_t spt,
                              const uint32_t *__restrict__ sums, const uint32_t *__restrict__ k_n,
                              const uint32_t *__restrict__ blk_sz, uint32_t *__restrict__ tile_sz,
                              uint32_t *__restrict__ tile_hdr) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cnt) return;
-    const uint32_t tile = t0 + j;
+    if (j >= total) return;
+    const uint32_t tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
     uint64_t fsz = 4 + 4 + 4ull * k_n[tile];
     for (uint32_t c = 0; c < spt; c++) fsz += blk_sz[(uint64_t)tile * 10 + c];
@@ -48,11 +49,14 @@ __global__ void k_tile_sizes(const TileDesc *__restrict__ tiles, uint32_t t0, ui
     else { tile_sz[j] = (uint32_t)raw; tile_hdr[j] = (uint32_t)raw; }                                                  // libxpng.c:566
 }
 
-// K5b  exclusive scan of tile sizes -> byte offsets, total at off[cnt].  Single workgroup.
-__global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restrict__ tile_sz, uint32_t cnt,
-                                                       uint64_t *__restrict__ off) {
+// K5b  exclusive scan of tile sizes -> byte offsets inside each image's blob buffer.  One workgroup per image:
+// off[img * (cnt + 1) + i], the image's total at index cnt and in totals[img].
+__global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restrict__ tile_sz_all, uint32_t cnt,
+                                                       uint64_t *__restrict__ off_all, uint64_t *__restrict__ totals) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_base;
+    const uint32_t *tile_sz = tile_sz_all + (uint64_t)blockIdx.x * cnt;
+    uint64_t *off = off_all + (uint64_t)blockIdx.x * (cnt + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
         if (tid == 1023) s_base = base + incl;
         __syncthreads();
     }
-    if (tid == 0) off[cnt] = s_base;
+    if (tid == 0) { off[cnt] = s_base; totals[blockIdx.x] = s_base; }
 }
 
 __device__ __forceinline__ void block_copy(uint8_t *dst, const uint8_t *src, uint64_t bytes) {
@@ -89,14 +93,15 @@ __device__ __forceinline__ void block_copy(uint8_t *dst, const uint8_t *src, uin
 }
 
 // K5c  gather every tile's pieces to its final place.  grid = tiles, block = 256.
-__global__ __launch_bounds__(256) void k_tile_gather(const uint8_t *__restrict__ raster, uint64_t bpr, int pxsz,
-                                                     const TileDesc *__restrict__ tiles, uint32_t t0, uint32_t spt,
+__global__ __launch_bounds__(256) void k_tile_gather(const uint8_t *const *__restrict__ rasters, uint64_t bpr, int pxsz,
+                                                     const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
                                                      const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ k_n,
                                                      const uint32_t *__restrict__ blk_sz, const uint32_t *__restrict__ tile_hdr,
-                                                     const uint64_t *__restrict__ off, uint8_t *__restrict__ blobs) {
-    const uint32_t j = blockIdx.x, tile = t0 + j;
+                                                     const uint64_t *__restrict__ off, uint8_t *const *__restrict__ blobs) {
+    const uint32_t j = blockIdx.x, tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
-    uint8_t *dst = blobs + off[j];
+    const uint8_t *__restrict__ raster = rasters[t.img];
+    uint8_t *dst = blobs[t.img] + off[(uint64_t)(j / sel.cnt) * (sel.cnt + 1) + j % sel.cnt];
     const uint32_t hdr = tile_hdr[j];
     if (threadIdx.x < 4) dst[threadIdx.x] = (uint8_t)(hdr >> (8 * threadIdx.x));
     if ((hdr >> 24) == 0) {  // raw tile: rows (libxpng.c:566-567)

@@ -62,7 +62,7 @@ static void build_tiles(uint64_t W, uint64_t H, std::vector<TileDesc> &out) {
             t.y = (uint32_t)y; t.h = (uint32_t)th;
             t.n = t.w * t.h;
             t.pbase = pbase; t.sbase = sbase;
-            pbase += rup(t.n + 8, 256);
+            pbase += rup(t.n + 64, 256);
             sbase += tile_scratch_bytes(t.n);
             out.push_back(t);
         }
@@ -73,19 +73,23 @@ struct xpnghip_ctx {
     int device = 0;
     uint64_t W = 0, H = 0;
     int pxsz = 0;
+    uint32_t B = 1;    // images per launch (native batching: virtual tile = image * N + tile)
     uint32_t spt = 0;  // streams per tile: 9 (+1 alpha)
-    std::vector<TileDesc> tiles;
-    uint64_t plane_stride = 0, scratch_bytes = 0, ws_bytes = 0;
-    uint32_t max_n = 0;
+    std::vector<TileDesc> tiles;  // the N tiles of ONE image (host copy); the device table has B * N entries
+    uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
     TileDesc *d_tiles = nullptr;
     uint8_t *d_planes = nullptr, *d_scratch = nullptr;
     uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
-    uint64_t *d_off = nullptr;
-    uint64_t *h_total = nullptr;  // pinned
+    uint64_t *d_off = nullptr, *d_totals = nullptr, *d_dbg = nullptr;
+    const uint8_t **d_in_ptrs = nullptr;  // B raster (encode) / blob (decode) pointers
+    uint8_t **d_out_ptrs = nullptr;       // B blob (encode) / raster (decode) pointers
+    std::vector<const void *> h_in_ptrs;  // what d_in_ptrs / d_out_ptrs currently hold (skip the upload when unchanged)
+    std::vector<void *> h_out_ptrs;
+    int stamps = 0;  // XPNG_STAMPS=1: chain kernels record s_memtime phase stamps (debug_fetch 40/41)
+    uint64_t *h_total = nullptr;  // pinned, B entries
     hipStream_t stream = nullptr;
     // host-buffer wrappers keep their own device raster / blob buffers here
     uint8_t *d_raster = nullptr, *d_blobs = nullptr;
-    uint64_t last_t0 = 0, last_t1 = 0;
     DecodeWs dec;
 };
 
@@ -93,8 +97,8 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz,
-                    c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_raster, c->d_blobs};
+    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
+                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     decode_ws_free(c->dec);
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -102,18 +106,25 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     delete c;
 }
 
-extern "C" int xpnghip_ctx_create(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz) {
-    if (!out || !w || !h || w > (1u << 24) || h > (1u << 24) || (pxsz != 3 && pxsz != 4)) return fail("bad arguments");
+extern "C" int xpnghip_ctx_create_batch(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch) {
+    if (!out || !w || !h || w > (1u << 24) || h > (1u << 24) || (pxsz != 3 && pxsz != 4) || batch < 1 || batch > 4096) return fail("bad arguments");
     if (xpnghip_device_count() <= device || device < 0) return fail("no such HIP device (libxpng_hip has no CPU fallback)");
     HIPCHK(hipSetDevice(device));
     xpnghip_ctx *c = new xpnghip_ctx();
-    c->device = device; c->W = w; c->H = h; c->pxsz = pxsz; c->spt = pxsz == 4 ? 10 : 9;
+    c->device = device; c->W = w; c->H = h; c->pxsz = pxsz; c->spt = pxsz == 4 ? 10 : 9; c->B = batch;
     build_tiles(w, h, c->tiles);
-    const uint64_t N = c->tiles.size();
+    const uint64_t N = c->tiles.size(), VN = N * batch;
     const TileDesc &last = c->tiles.back();
-    c->plane_stride = last.pbase + rup(last.n + 8, 256);
-    c->scratch_bytes = last.sbase + tile_scratch_bytes(last.n);
-    for (auto &t : c->tiles) c->max_n = t.n > c->max_n ? t.n : c->max_n;
+    c->plane_img = last.pbase + rup(last.n + 64, 256);
+    c->scratch_img = last.sbase + tile_scratch_bytes(last.n);
+    c->plane_stride = c->plane_img * batch;
+    std::vector<TileDesc> all(VN);
+    for (uint32_t b = 0; b < batch; b++)
+        for (uint64_t i = 0; i < N; i++) {
+            TileDesc t = c->tiles[i];
+            t.img = b; t.pbase += b * c->plane_img; t.sbase += b * c->scratch_img;
+            all[b * N + i] = t;
+        }
 #define ALLOC(ptr, bytes)                                                                          \
     do {                                                                                           \
         if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) {                                   \
@@ -122,27 +133,36 @@ extern "C" int xpnghip_ctx_create(xpnghip_ctx **out, int device, uint64_t w, uin
         }                                                                                          \
         c->ws_bytes += (bytes);                                                                    \
     } while (0)
-    ALLOC(c->d_tiles, N * sizeof(TileDesc));
-    ALLOC(c->d_planes, 5 * c->plane_stride);
-    ALLOC(c->d_scratch, c->scratch_bytes);
-    ALLOC(c->d_sums, N * 16);
-    ALLOC(c->d_ctx_n, N * 9 * 4);
-    ALLOC(c->d_k_n, N * 4);
-    ALLOC(c->d_blk_sz, N * 10 * 4);
-    ALLOC(c->d_tile_sz, N * 4);
-    ALLOC(c->d_tile_hdr, N * 4);
-    ALLOC(c->d_off, (N + 1) * 8);
+    ALLOC(c->d_tiles, VN * sizeof(TileDesc));
+    ALLOC(c->d_planes, 5 * c->plane_stride + 8192);   // + slack: LDS-ring staging reads whole 1 KB units
+    ALLOC(c->d_scratch, c->scratch_img * batch + 8192);
+    ALLOC(c->d_sums, VN * 16);
+    ALLOC(c->d_ctx_n, VN * 9 * 4);
+    ALLOC(c->d_k_n, VN * 4);
+    ALLOC(c->d_blk_sz, VN * 10 * 4);
+    ALLOC(c->d_tile_sz, VN * 4);
+    ALLOC(c->d_tile_hdr, VN * 4);
+    ALLOC(c->d_off, (VN + batch) * 8);
+    ALLOC(c->d_totals, (uint64_t)batch * 8);
+    ALLOC(c->d_dbg, VN * 10 * 8 * 8 * 2);
+    ALLOC(c->d_in_ptrs, (uint64_t)batch * 8);
+    ALLOC(c->d_out_ptrs, (uint64_t)batch * 8);
 #undef ALLOC
-    if (hipHostMalloc((void **)&c->h_total, 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipMemcpy(c->d_tiles, c->tiles.data(), N * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess) {
+    c->stamps = getenv("XPNG_STAMPS") != nullptr;
+    if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipMemcpy(c->d_tiles, all.data(), VN * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess) {
         xpnghip_ctx_destroy(c);
         return fail("context setup failed");
     }
     *out = c;
     return 0;
 }
+extern "C" int xpnghip_ctx_create(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz) {
+    return xpnghip_ctx_create_batch(out, device, w, h, pxsz, 1);
+}
 
 extern "C" uint64_t xpnghip_ctx_tile_count(const xpnghip_ctx *c) { return c ? c->tiles.size() : 0; }
+extern "C" uint32_t xpnghip_ctx_batch(const xpnghip_ctx *c) { return c ? c->B : 0; }
 extern "C" int xpnghip_ctx_tile(const xpnghip_ctx *c, uint64_t i, uint64_t xywh[4]) {
     if (!c || i >= c->tiles.size()) return 1;
     xywh[0] = c->tiles[i].x; xywh[1] = c->tiles[i].y; xywh[2] = c->tiles[i].w; xywh[3] = c->tiles[i].h;
@@ -161,77 +181,104 @@ static int check_range(const xpnghip_ctx *c, uint64_t t0, uint64_t t1) {
     return 0;
 }
 
-// chooser + transform (BASELINE config 2).  Launch only; no sync.
+// upload the per-image pointer tables (only when they changed: the copy comes from pageable host memory)
+static int set_ptrs(xpnghip_ctx *c, const void *const *in, void *const *outp, uint32_t nimg, hipStream_t s) {
+    if (nimg < 1 || nimg > c->B) return fail("batch size exceeds the context's batch");
+    bool same = c->h_in_ptrs.size() == nimg && c->h_out_ptrs.size() == nimg;
+    for (uint32_t b = 0; same && b < nimg; b++) same = c->h_in_ptrs[b] == in[b] && c->h_out_ptrs[b] == outp[b];
+    if (same) return 0;
+    for (uint32_t b = 0; b < nimg; b++)
+        if (((uintptr_t)in[b] & 15) || ((uintptr_t)outp[b] & 3)) return fail("device buffers must be 16-byte aligned");
+    HIPCHK(hipMemcpyAsync(c->d_in_ptrs, in, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_out_ptrs, outp, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    c->h_in_ptrs.assign(in, in + nimg);
+    c->h_out_ptrs.assign(outp, outp + nimg);
+    return 0;
+}
+
+// chooser + transform (BASELINE config 2).  Launch only; no sync.  d_in_ptrs already holds the raster pointers.
 template <int PXSZ>
-static int launch_transform(xpnghip_ctx *c, const uint8_t *d_raster, uint32_t t0, uint32_t t1, hipStream_t s) {
-    const uint32_t cnt = t1 - t0;
+static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+    const uint32_t cnt = t1 - t0, total = nimg * cnt;
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
-    HIPCHK(hipMemsetAsync(c->d_sums + (uint64_t)t0 * 4, 0, (uint64_t)cnt * 16, s));
+    if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
+    else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
     const uint32_t strips = 8;
-    k_chooser<PXSZ><<<cnt * strips, 256, 0, s>>>(d_raster, bpr, c->d_tiles, t0, strips, c->d_sums);
+    k_chooser<PXSZ><<<total * strips, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, strips, c->d_sums);
     const uint32_t bpt = (max_n + 1023) / 1024;
-    k_m1_transform_generic<PXSZ><<<cnt * bpt, 256, 0, s>>>(d_raster, bpr, c->d_tiles, t0, bpt, c->d_sums, c->d_planes, c->plane_stride);
+    k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 extern "C" int xpnghip_m1_transform_device(xpnghip_ctx *c, const void *d_raster, uint64_t t0, uint64_t t1, void *stream) {
     if (check_range(c, t0, t1)) return 1;
-    if ((uintptr_t)d_raster & 15) return fail("device raster must be 16-byte aligned");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    c->last_t0 = t0; c->last_t1 = t1;
-    return c->pxsz == 4 ? launch_transform<4>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, s)
-                        : launch_transform<3>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, s);
+    void *dummy = c->d_out_ptrs;  // no output buffer in this stage
+    if (set_ptrs(c, &d_raster, &dummy, 1, s)) return 1;
+    return c->pxsz == 4 ? launch_transform<4>(c, 1, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, 1, (uint32_t)t0, (uint32_t)t1, s);
 }
 
 template <int PXSZ>
-static int launch_encode_m1(xpnghip_ctx *c, const uint8_t *d_raster, uint32_t t0, uint32_t t1, uint8_t *d_blobs, hipStream_t s) {
-    const uint32_t cnt = t1 - t0;
+static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+    const uint32_t cnt = t1 - t0, total = nimg * cnt;
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
     const uint64_t bpr = c->W * PXSZ;
-    if (launch_transform<PXSZ>(c, d_raster, t0, t1, s)) return 1;
-    k_m1_streams<PXSZ><<<cnt, ST_THREADS, 0, s>>>(d_raster, bpr, c->d_tiles, t0, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    k_rans2_encode<<<cnt * c->spt, 64, 0, s>>>(c->d_tiles, t0, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz);
-    k_tile_sizes<<<(cnt + 255) / 256, 256, 0, s>>>(c->d_tiles, t0, cnt, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
-    k_tile_offsets<<<1, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off);
-    k_tile_gather<<<cnt, 256, 0, s>>>(d_raster, bpr, PXSZ, c->d_tiles, t0, c->spt, c->d_scratch, c->d_k_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, d_blobs);
+    if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
+    k_m1_streams<PXSZ><<<total, ST_THREADS, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
+    k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
+    k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
+    k_tile_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_total, c->d_off + cnt, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
     return 0;
 }
 
-extern "C" int xpnghip_encode_device(xpnghip_ctx *c, int mode, const void *d_raster, uint64_t t0, uint64_t t1,
-                                     void *d_blobs, uint64_t *blobs_len, void *stream) {
+extern "C" int xpnghip_encode_device_batch(xpnghip_ctx *c, int mode, const void *const *d_rasters, uint32_t nimg, uint64_t t0,
+                                           uint64_t t1, void *const *d_blobs, uint64_t *blobs_len, void *stream) {
     if (check_range(c, t0, t1)) return 1;
     if (mode != 1) return fail("only mode 1 is implemented on the device in this build");
-    if ((uintptr_t)d_raster & 15 || (uintptr_t)d_blobs & 15) return fail("device buffers must be 16-byte aligned");
     if (c->pxsz == 4)
         for (uint64_t i = t0; i < t1; i++)
             if (c->tiles[i].w < 4 || c->tiles[i].h < 4) return fail("RGBA tile narrower than 4 px: undefined in the reference; store level 7");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    c->last_t0 = t0; c->last_t1 = t1;
-    const int rc = c->pxsz == 4 ? launch_encode_m1<4>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, (uint8_t *)d_blobs, s)
-                                : launch_encode_m1<3>(c, (const uint8_t *)d_raster, (uint32_t)t0, (uint32_t)t1, (uint8_t *)d_blobs, s);
+    if (set_ptrs(c, d_rasters, d_blobs, nimg, s)) return 1;
+    const int rc = c->pxsz == 4 ? launch_encode_m1<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_encode_m1<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
     if (rc) return rc;
     if (blobs_len) {
         HIPCHK(hipStreamSynchronize(s));
-        *blobs_len = *c->h_total;
+        for (uint32_t b = 0; b < nimg; b++) blobs_len[b] = c->h_total[b];
     }
     return 0;
 }
-extern "C" uint64_t xpnghip_ctx_last_blobs_len(xpnghip_ctx *c) { return c ? *c->h_total : 0; }
+extern "C" int xpnghip_encode_device(xpnghip_ctx *c, int mode, const void *d_raster, uint64_t t0, uint64_t t1,
+                                     void *d_blobs, uint64_t *blobs_len, void *stream) {
+    return xpnghip_encode_device_batch(c, mode, &d_raster, 1, t0, t1, &d_blobs, blobs_len, stream);
+}
+extern "C" uint64_t xpnghip_ctx_last_blobs_len(xpnghip_ctx *c) { return c ? c->h_total[0] : 0; }
+extern "C" uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *c, uint32_t img) { return c && img < c->B ? c->h_total[img] : 0; }
 
-extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
-                                     const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
+extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void *const *d_blobs, uint32_t nimg,
+                                           const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *const *d_rasters, void *stream) {
     if (check_range(c, t0, t1)) return 1;
     if (mode != 1) return fail("only mode 1 is implemented on the device in this build");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    return decode_m1_launch(c->dec, c->tiles, c->d_tiles, c->W, c->pxsz, (const uint8_t *)d_blobs, blobs_len, tile_off,
-                            (uint32_t)t0, (uint32_t)t1, (uint8_t *)d_raster, s, g_err);
+    if (set_ptrs(c, d_blobs, d_rasters, nimg, s)) return 1;
+    return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, c->pxsz, c->d_in_ptrs, tile_off,
+                            (uint32_t)t0, (uint32_t)t1, c->d_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr);
+}
+extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
+                                     const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
+    (void)blobs_len;
+    return xpnghip_decode_device_batch(c, mode, &d_blobs, 1, tile_off, t0, t1, &d_raster, stream);
 }
 
 // ---- host-buffer wrappers ------------------------------------------------------------------------------
@@ -319,6 +366,8 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
         if ((uint32_t)(what - 20) >= c->spt) return 0;
         if (!d2h(tmp, c->d_blk_sz + tile * 10, 40)) return -1;
         src = c->d_scratch + t.sbase + off_blk(t.n, what - 20); bytes = tmp[what - 20];
+    } else if (what == 40 || what == 41) {
+        src = (const uint8_t *)(c->d_dbg + ((what - 40) * c->tiles.size() * c->B + tile) * 80); bytes = 640;
     } else if (what == 30) {
         src = (const uint8_t *)(c->d_sums + tile * 4); bytes = 16;
     } else return -1;

@@ -1,0 +1,77 @@
+"""Tile-range sharding of one raster over torch.distributed ranks.
+
+Tiles are coded independently (own first pixel, predictor flags and statistics: reference libxpng.c:542-570,
+840-862), so a rank encodes a contiguous tile-index range with no data-path collective.  The only exchange
+is the final concatenation (reference libxpng.c:764-769): an all-gather of per-rank byte counts, then a
+gatherv of the blob bytes to rank 0 as grouped point-to-point sends (RCCL ncclSend/ncclRecv over xGMI on
+the GPU box, gloo on CPU for the tests).  No all-reduce, no ring.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def tile_ranges(n_tiles: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges [floor(k*T/G), floor((k+1)*T/G))."""
+    return [(k * n_tiles // world, (k + 1) * n_tiles // world) for k in range(world)]
+
+
+def weighted_tile_ranges(tiles: Sequence[Tuple[int, int, int, int]], world: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges balanced by pixel count (first-row / first-column tiles are up to 2.25x larger)."""
+    total = sum(t[2] * t[3] for t in tiles)
+    out, start, acc, k = [], 0, 0, 1
+    for i, t in enumerate(tiles):
+        acc += t[2] * t[3]
+        while k < world and acc >= total * k / world and i + 1 <= len(tiles) - (world - k):
+            out.append((start, i + 1))
+            start = i + 1
+            k += 1
+    out.append((start, len(tiles)))
+    while len(out) < world:
+        out.append((len(tiles), len(tiles)))
+    return out
+
+
+def band_rows(tiles: Sequence[Tuple[int, int, int, int]], t0: int, t1: int) -> Tuple[int, int]:
+    """Raster rows [y0, y1) touched by tiles [t0, t1): a rank only needs this band in HBM."""
+    if t0 >= t1:
+        return 0, 0
+    return min(t[1] for t in tiles[t0:t1]), max(t[1] + t[3] for t in tiles[t0:t1])
+
+
+def gather_blobs(local, local_len: int, group=None, dst: int = 0):
+    """gatherv of per-rank blob bytes to rank `dst`.
+
+    local: 1-D uint8 tensor (device for RCCL, CPU for gloo) holding this rank's concatenated tile blobs in its
+    first `local_len` bytes.  Returns (tensor_with_all_blobs_in_rank_order or None, list_of_lengths).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lens_t = torch.zeros(world, dtype=torch.int64, device=local.device)
+    mine = torch.tensor([local_len], dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(lens_t, mine, group=group) if local.device.type == "cuda" else \
+        dist.all_gather(list(lens_t.split(1)), mine, group=group)
+    lens = [int(v) for v in lens_t.tolist()]
+    if world == 1:
+        return local[:local_len], lens
+    if rank == dst:
+        total = sum(lens)
+        out = torch.empty(total, dtype=torch.uint8, device=local.device)
+        ops, o = [], 0
+        for r in range(world):
+            seg = out[o:o + lens[r]]
+            if r == dst:
+                seg.copy_(local[:local_len])
+            elif lens[r]:
+                ops.append(dist.P2POp(dist.irecv, seg, r, group))
+            o += lens[r]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out, lens
+    if local_len:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_len].contiguous(), dst, group)]):
+            req.wait()
+    return None, lens
