@@ -87,6 +87,8 @@ int xpnghip_decode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d
 /* Stage-only run for BASELINE config 2: predictor chooser + per-pixel transform (libxpng.c:92-140 and
  * the arithmetic of 497-519) over tiles [t0, t1); symbol planes stay in the context's workspace. */
 int xpnghip_m1_transform_device(xpnghip_ctx *ctx, const void *d_raster, uint64_t t0, uint64_t t1, void *stream);
+int xpnghip_m1_transform_device_batch(xpnghip_ctx *ctx, const void *const *d_rasters, uint32_t nimg, uint64_t t0,
+                                      uint64_t t1, void *stream);
 
 /* ---- introspection for parity tests (copies intermediates of the LAST encode to host) --------------
  * what: 0 = predictor byte pr (1 B), 1..5 = planes nl,r,g,b,a (w*h B each, tile-linear),

@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "xpnghip_ctx_tile", "xpnghip_ctx_blob_bound", "xpnghip_ctx_workspace_bytes", "xpnghip_encode_device",
     "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
     "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
-    "xpnghip_decode_device_batch",
+    "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -91,6 +91,8 @@ def hip_lib():
         L.xpnghip_decode_device.argtypes = [vp, C.c_int, vp, u64, C.POINTER(u64), u64, u64, vp, vp]
         L.xpnghip_m1_transform_device.restype = C.c_int
         L.xpnghip_m1_transform_device.argtypes = [vp, vp, u64, u64, vp]
+        L.xpnghip_m1_transform_device_batch.restype = C.c_int
+        L.xpnghip_m1_transform_device_batch.argtypes = [vp, C.POINTER(vp), C.c_uint32, u64, u64, vp]
         L.xpnghip_debug_fetch.restype = C.c_int64
         L.xpnghip_debug_fetch.argtypes = [vp, C.c_int, u64, vp, u64]
         _hip = L
@@ -248,6 +250,12 @@ class Context:
     def transform_device(self, d_raster: int, t0=0, t1=None, stream=0):
         if hip_lib().xpnghip_m1_transform_device(self._h, d_raster, t0, self.n_tiles if t1 is None else t1, stream):
             raise XpngError("xpnghip_m1_transform_device: " + _err())
+
+    def transform_device_batch(self, d_rasters, t0=0, t1=None, stream=0):
+        k = len(d_rasters)
+        ins = (C.c_void_p * k)(*d_rasters)
+        if hip_lib().xpnghip_m1_transform_device_batch(self._h, ins, k, t0, self.n_tiles if t1 is None else t1, stream):
+            raise XpngError("xpnghip_m1_transform_device_batch: " + _err())
 
     def fetch(self, what, tile: int, cap: int = 1 << 22) -> np.ndarray:
         code = self.FETCH[what] if isinstance(what, str) else what

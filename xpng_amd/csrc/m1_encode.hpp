@@ -30,12 +30,18 @@ __global__ __launch_bounds__(256) void k_chooser(const uint8_t *const *__restric
     const uint32_t j0 = (uint32_t)((uint64_t)ys * strip / strips), j1 = (uint32_t)((uint64_t)ys * (strip + 1) / strips);
     const uint32_t cnt = (j1 - j0) * xs;
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const bool pair_loads = PXSZ == 4 && (t.x & 1u) == 0 && (bpr & 7u) == 0;  // pixel x-1 (x % 4 == 3) is then 8-byte aligned: L|cur and UL|U in one load each
     for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
         const uint32_t j = j0 + idx / xs, i = idx - (idx / xs) * xs;
         const uint8_t *p = raster + (uint64_t)(t.y + 4 * j + 3) * bpr + (uint64_t)(t.x + 4 * i + 3) * PXSZ;
-        const uint32_t cur = load_px<PXSZ>(p);
+        uint32_t cur, L, U, UL;
+        if (pair_loads) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(p - 4), b = *reinterpret_cast<const uint2 *>(p - bpr - 4);
+            L = a.x; cur = a.y; UL = b.x; U = b.y;
+        } else {
+            cur = load_px<PXSZ>(p); L = load_px<PXSZ>(p - PXSZ); U = load_px<PXSZ>(p - bpr); UL = load_px<PXSZ>(p - bpr - PXSZ);
+        }
         if (PXSZ == 4 && (cur >> 24) == 0) continue;  // libxpng.c:121
-        const uint32_t L = load_px<PXSZ>(p - PXSZ), U = load_px<PXSZ>(p - bpr), UL = load_px<PXSZ>(p - bpr - PXSZ);
         int d2[3], d3[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -135,6 +141,183 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
     *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
     *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
     if (PXSZ == 4) *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+}
+
+// ---- byte-parallel (SWAR) forms of the per-pixel arithmetic for interior RGBA pixels: all four channels of a pixel
+// move through one 32-bit register (r | g<<8 | b<<16 | a<<24).
+__device__ __forceinline__ uint32_t swar_sub8(uint32_t a, uint32_t b) {  // per-byte a - b (mod 256)
+    return ((a | 0x80808080u) - (b & 0x7F7F7F7Fu)) ^ ((a ^ ~b) & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t swar_zigzag8(uint32_t d) {  // per byte: v = (int8)d; (v << 1) ^ (v >> 7)   (pix_toU)
+    const uint32_t sgn = (d >> 7) & 0x01010101u;
+    return ((d << 1) & 0xFEFEFEFEu) ^ ((sgn << 8) - sgn);
+}
+// interior pixel (row > 0, column > 0): returns the zig-zag word (zr | zg<<8 | zb<<16 | za<<24) and nl.
+__device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, int useGrad, int useG,
+                                                      uint32_t &nl) {
+    uint32_t pred;
+    if (!useGrad) {
+        pred = __builtin_amdgcn_lerp(L, U, 0x01010101u);  // per byte (L + U + 1) >> 1   (p2a)
+    } else {                                               // p3a per colour channel, low 8 bits
+        pred = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int l = (L >> (8 * c)) & 255, u = (U >> (8 * c)) & 255, ul = (UL >> (8 * c)) & 255;
+            pred |= ((uint32_t)pred_grad(l, u, ul) & 255u) << (8 * c);
+        }
+    }
+    pred = (pred & 0x00FFFFFFu) | (L & 0xFF000000u);  // alpha always predicts from the left (libxpng.c:511)
+    uint32_t d = swar_sub8(cur, pred);
+    if (useG) {                                        // r -= g, b -= g on the residuals (libxpng.c:513)
+        const uint32_t g = (d >> 8) & 0xFFu;
+        d = swar_sub8(d, g | (g << 16));
+    }
+    uint32_t z = swar_zigzag8(d);
+    const uint32_t m = (z | (z >> 8) | (z >> 16)) & 0xFFu;
+    nl = (uint32_t)bit_width(m);
+    if ((cur >> 24) == 0) { nl = NL_NONE; z &= 0xFF000000u; }  // invisible pixel: alpha symbol only (libxpng.c:502)
+    return z;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K2 (fast form, RGBA)  LDS-staged per-pixel transform.  One 256-thread workgroup = a strip of TR_ROWS rows of one tile:
+//   phase 1  rows y0-1 .. y0+R-1 of the tile are copied global -> LDS with coalesced 16-byte loads (the halo row is the
+//            only re-read: 1/TR_ROWS of the traffic); every row keeps its global 16-byte phase, so a pixel is one aligned
+//            LDS dword;
+//   phase 2  one thread = 4 consecutive pixels of the tile in raster order: cur / left / up / up-left come from LDS
+//            (10 dword reads per 4 pixels when the group sits in one row), the five symbol bytes of the 4 pixels are
+//            packed into one dword per plane and stored coalesced (256 B per wave instruction).
+// Tiles wider than TR_MAXW pixels (images narrower / flatter than 444 px) use the generic kernel.
+constexpr uint32_t TR_ROWS = 16, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
+
+__global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                           uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                           uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
+                                                           uint8_t *__restrict__ planes, uint64_t plane_stride) {
+    __shared__ __align__(16) uint8_t rows[(TR_ROWS + 1) * TR_PITCH];
+    const uint32_t tile = vtile(sel, blockIdx.x / strips_per_tile), strip = blockIdx.x % strips_per_tile;
+    const TileDesc t = tiles[tile];
+    const uint32_t y0 = strip * TR_ROWS;
+    if (y0 >= t.h) return;
+    const uint8_t *__restrict__ raster = rasters[t.img];
+    const uint32_t nrows = min(TR_ROWS, t.h - y0);
+    const uint32_t first = y0 ? y0 - 1 : 0, lrows = y0 + nrows - first;  // rows staged: [first, first + lrows)
+    // ---- phase 1: global -> LDS, 16 bytes per lane per load
+    {
+        const uint64_t g0 = (uint64_t)(t.y + first) * bpr + (uint64_t)t.x * 4;  // first staged byte
+        const uint32_t row_bytes = t.w * 4;
+        const uint32_t chunks = (uint32_t)(((g0 & 15) + row_bytes + 15) >> 4) + ((bpr & 15) ? 1 : 0);  // per row, upper bound
+        // All of a thread's loads are issued before the first LDS store: ~8 x 16 B in flight per thread (Little's law:
+        // 6 TB/s x ~2 us of loaded latency needs ~50 KB in flight per CU).
+        constexpr int LD = 12;  // (TR_ROWS + 1) * (TR_MAXW * 4 / 16 + 1) / 256 rounded up
+        const uint32_t total_chunks = lrows * chunks;
+        const float inv_chunks = 1.0f / (float)chunks;
+        uint4 v[LD];
+        uint32_t dst[LD];
+#pragma unroll
+        for (int k = 0; k < LD; k++) {
+            const uint32_t idx = threadIdx.x + 256u * k;
+            dst[k] = ~0u;
+            if (idx < total_chunks) {
+                uint32_t r = (uint32_t)((float)idx * inv_chunks);
+                if (r * chunks > idx) r--;
+                if ((r + 1) * chunks <= idx) r++;
+                const uint32_t ch = idx - r * chunks;
+                const uint64_t gr = g0 + (uint64_t)r * bpr;           // first byte of this row's segment
+                const uint64_t a = (gr & ~15ull) + (uint64_t)ch * 16;  // 16-byte aligned chunk
+                if (a < gr + row_bytes) {
+                    dst[k] = r * TR_PITCH + ch * 16;
+                    if (a + 16 <= raster_bytes) v[k] = *reinterpret_cast<const uint4 *>(raster + a);
+                    else {  // last chunk of the raster: stay inside the allocation
+                        uint32_t w4[4] = {0, 0, 0, 0};
+                        for (uint32_t q = 0; q < 4; q++) if (a + 4 * q + 4 <= raster_bytes) w4[q] = *reinterpret_cast<const uint32_t *>(raster + a + 4 * q);
+                        v[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
+    }
+    __syncthreads();
+    // ---- phase 2
+    const int pr = pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h);
+    const int useGrad = (pr >> 1) & 1, useG = pr & 1;
+    const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
+    const float inv_w = 1.0f / (float)t.w;
+    for (uint32_t g = threadIdx.x; g < groups; g += 256) {
+        const uint32_t j0 = g * 4;  // pixel index inside the strip
+        uint32_t yy = (uint32_t)((float)j0 * inv_w);
+        if (yy * t.w > j0) yy--;
+        if ((yy + 1) * t.w <= j0) yy++;
+        uint32_t x = j0 - yy * t.w;
+        uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
+        const uint32_t lr = yy + (y0 - first);  // LDS row of pixel row yy
+        const uint32_t sh = (uint32_t)(((uint64_t)(t.y + first + lr) * bpr + (uint64_t)t.x * 4) & 15);
+        const uint32_t *rowc = reinterpret_cast<const uint32_t *>(rows + lr * TR_PITCH + sh);
+        if (x + 3 < t.w && j0 + 3 < strip_px && (bpr & 15) == 0) {
+            // whole group in one row (and every row has the same 16-byte phase): 5 + 5 dwords
+            const uint32_t *rowu = reinterpret_cast<const uint32_t *>(rows + (lr ? lr - 1 : 0) * TR_PITCH + sh);
+            const bool row0 = (y0 + yy) == 0;
+            uint32_t c[5], u[5];
+            c[0] = x ? rowc[x - 1] : 0u;
+            u[0] = (x && !row0) ? rowu[x - 1] : 0u;
+            if (sh == 0) {  // 16-byte aligned group: one ds_read_b128 per row (dword reads at a 16-byte lane stride are 4-way bank conflicts)
+                const uint4 cc = *reinterpret_cast<const uint4 *>(rowc + x);
+                const uint4 uu = row0 ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(rowu + x);
+                c[1] = cc.x; c[2] = cc.y; c[3] = cc.z; c[4] = cc.w;
+                u[1] = uu.x; u[2] = uu.y; u[3] = uu.z; u[4] = uu.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { c[k + 1] = rowc[x + k]; u[k + 1] = row0 ? 0u : rowu[x + k]; }
+            }
+            if (!row0 && x > 0) {  // interior group: byte-parallel arithmetic, then a 4x4 byte transpose into the planes
+                uint32_t z[4], n4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior(c[k + 1], c[k], u[k + 1], u[k], useGrad, useG, n4[k]);
+                onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
+                const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);  // z0.b0 z1.b0 z0.b1 z1.b1
+                const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);  // z0.b2 z1.b2 z0.b3 z1.b3
+                const uint32_t t23lo = __builtin_amdgcn_perm(z[3], z[2], 0x05010400u);
+                const uint32_t t23hi = __builtin_amdgcn_perm(z[3], z[2], 0x07030602u);
+                orr = __builtin_amdgcn_perm(t23lo, t01lo, 0x05040100u);  // b0 of z0..z3
+                og = __builtin_amdgcn_perm(t23lo, t01lo, 0x07060302u);   // b1
+                ob = __builtin_amdgcn_perm(t23hi, t01hi, 0x05040100u);   // b2
+                oa = __builtin_amdgcn_perm(t23hi, t01hi, 0x07060302u);   // b3
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+                    if (y0 + yy + x + k != 0) m1_pixel<4>(c[k + 1], c[k], u[k + 1], u[k], row0, x + k == 0, useGrad, useG, nl, zr, zg, zb, za);
+                    onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+                }
+            }
+        } else {
+            uint32_t y = yy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+                if (j0 + k < strip_px && (y0 + y + x) != 0) {
+                    const uint32_t l2 = y + (y0 - first);
+                    const uint32_t s2 = (uint32_t)(((uint64_t)(t.y + first + l2) * bpr + (uint64_t)t.x * 4) & 15);
+                    const uint32_t s1 = l2 ? (uint32_t)(((uint64_t)(t.y + first + l2 - 1) * bpr + (uint64_t)t.x * 4) & 15) : 0u;
+                    const uint32_t *rc = reinterpret_cast<const uint32_t *>(rows + l2 * TR_PITCH + s2);
+                    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rows + (l2 ? l2 - 1 : 0) * TR_PITCH + s1);
+                    const bool row0 = (y0 + y) == 0, col0 = x == 0;
+                    const uint32_t cur = rc[x], L = col0 ? 0u : rc[x - 1], U = row0 ? 0u : ru[x], UL = (row0 || col0) ? 0u : ru[x - 1];
+                    m1_pixel<4>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
+                }
+                onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+                if (++x == t.w) { x = 0; y++; }
+            }
+        }
+        const uint64_t o = t.pbase + (uint64_t)y0 * t.w + j0;
+        *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
+        *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
+        *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
+        *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
+        *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+    }
 }
 
 // --------------------------------------------------------------------------------------------------

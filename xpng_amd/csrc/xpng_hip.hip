@@ -207,10 +207,17 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
     if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
     else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
-    const uint32_t strips = 8;
+    const uint32_t strips = 16;
     k_chooser<PXSZ><<<total * strips, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, strips, c->d_sums);
-    const uint32_t bpt = (max_n + 1023) / 1024;
-    k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride);
+    uint32_t max_w = 0, max_h = 0;
+    for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
+    if (PXSZ == 4 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
+        const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
+        k_m1_transform_rgba<<<total * spt_, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride);
+    } else {
+        const uint32_t bpt = (max_n + 1023) / 1024;
+        k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -222,6 +229,15 @@ extern "C" int xpnghip_m1_transform_device(xpnghip_ctx *c, const void *d_raster,
     void *dummy = c->d_out_ptrs;  // no output buffer in this stage
     if (set_ptrs(c, &d_raster, &dummy, 1, s)) return 1;
     return c->pxsz == 4 ? launch_transform<4>(c, 1, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, 1, (uint32_t)t0, (uint32_t)t1, s);
+}
+
+extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *const *d_rasters, uint32_t nimg, uint64_t t0, uint64_t t1, void *stream) {
+    if (check_range(c, t0, t1)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    std::vector<void *> dummy(nimg, (void *)c->d_out_ptrs);  // no output buffers in this stage
+    if (set_ptrs(c, d_rasters, dummy.data(), nimg, s)) return 1;
+    return c->pxsz == 4 ? launch_transform<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
 }
 
 template <int PXSZ>
