@@ -38,14 +38,14 @@ def test_native_library_is_the_one_loaded(gpu):
     assert "xpng_amd/lib/libxpng_hip.so" in maps
 
 
-def test_store_matches_reference_goldens_level1_and_7(gpu, manifest, po, tmp_path):
-    """xpng_store (host C driver -> GPU tile codec) reproduces the reference's .xpng bytes for every small golden."""
+def test_store_matches_reference_goldens_all_levels(gpu, manifest, po, tmp_path):
+    """xpng_store (host C driver -> GPU tile codec) reproduces the reference's .xpng bytes for every small golden, at
+    levels 1 (FAST), 2 (SLOW: RGB through the 17-stream rANS v1 coder, gray and single-colour tiles; RGBA falls back to
+    level 1 as libxpng.c:755 does) and 7."""
     checked = 0
     for name, ent in small_entries(manifest):
         raster = golden_raster(name, ent)
-        stays_rgba = ent["ch"] == 4 and po.normalize_rgba(raster).shape[2] == 4
-        levels = [1, 7] + ([2] if stays_rgba else [])  # RGBA level 2 falls back to level 1 (libxpng.c:755)
-        for level in levels:
+        for level in (1, 2, 7):
             g = ent.get(f"L{level}")
             if g is None:
                 continue
@@ -56,7 +56,7 @@ def test_store_matches_reference_goldens_level1_and_7(gpu, manifest, po, tmp_pat
             if "file" in g:
                 assert data == open(os.path.join(GOLD, g["file"]), "rb").read()
             checked += 1
-    assert checked >= 250
+    assert checked >= 400
 
 
 def test_load_decodes_reference_goldens(gpu, manifest, po, tmp_path):
@@ -65,7 +65,7 @@ def test_load_decodes_reference_goldens(gpu, manifest, po, tmp_path):
     checked = 0
     for name, ent in small_entries(manifest):
         raster = golden_raster(name, ent)
-        for level in (1, 7):
+        for level in (1, 2, 7):
             g = ent.get(f"L{level}")
             if g is None:
                 continue
@@ -79,7 +79,7 @@ def test_load_decodes_reference_goldens(gpu, manifest, po, tmp_path):
             back = gpu.load(str(p))
             assert md5(to_seven_bytes(back)) == g["decoded_md5"], (name, level)
             checked += 1
-    assert checked >= 250
+    assert checked >= 400
 
 
 @pytest.mark.parametrize("kind,w,h,alpha", [("photo", 700, 500, True), ("photo", 1500, 1200, False), ("noise", 700, 500, True),
@@ -128,16 +128,17 @@ def test_transform_only_entry_point(gpu, po):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["synth_photo_4096x4096_rgba", "synth_photo_4096x4096_rgb", "synth_noise_4096x4096_rgba"])
-def test_full_size_4096_matches_reference_md5(gpu, manifest, name, tmp_path):
-    """BASELINE config 3 at full size: file md5 equals what the compiled reference wrote (manifest), and the
-    decode of that file returns the source raster."""
+@pytest.mark.parametrize("name,level", [("synth_photo_4096x4096_rgba", 1), ("synth_photo_4096x4096_rgb", 1), ("synth_photo_4096x4096_rgb", 2),
+                                        ("synth_noise_4096x4096_rgba", 1), ("synth_noise_4096x4096_rgb", 2)])
+def test_full_size_4096_matches_reference_md5(gpu, manifest, name, level, tmp_path):
+    """BASELINE config 3 at full size (photo RGBA at -1, photo RGB at -1 and -2, noise = raw tiles / level-7 rewrite): file md5
+    equals what the compiled reference wrote (manifest), and the decode of that file returns the source raster."""
     ent = manifest[name]
     raster = golden_raster(name, ent)
     out = tmp_path / "big.xpng"
-    gpu.store(1, raster, str(out))
+    gpu.store(level, raster, str(out))
     data = out.read_bytes()
-    assert len(data) == ent["L1"]["size"] and md5(data) == ent["L1"]["md5"]
+    assert len(data) == ent[f"L{level}"]["size"] and md5(data) == ent[f"L{level}"]["md5"]
     back = gpu.load(str(out))
     assert np.array_equal(back, raster)
 
@@ -161,17 +162,17 @@ def test_tile_range_sharding_concatenates_to_whole(gpu, po):
 
 
 def test_cli_roundtrip_like_reference_test_rb(gpu, manifest, tmp_path):
-    """reference test.rb:28-38: xpng -o src.7 res.xpng && xpng -d res.xpng res.7 && cmp src.7 res.7, o in {1,7}."""
+    """reference test.rb:28-38: xpng -o src.7 res.xpng && xpng -d res.xpng res.7 && cmp src.7 res.7, o in {1,2,7}."""
     from xpng_amd import api
     for name in ("img_pigz-logo", "crop_2021", "img_juicy"):
         src = os.path.join(GOLD, name + ".7")
-        for o in ("1", "7"):
+        for o in ("1", "2", "7"):
             res, back = tmp_path / "res.xpng", tmp_path / "res.7"
             r = subprocess.run([api.CLI, "-" + o, src, str(res)], capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
-            if o == "1":
+            if o != "7":
                 assert "encode," in r.stdout and "MPx/s" in r.stdout
-                assert md5(res.read_bytes()) == manifest[name]["L1"]["md5"]
+                assert md5(res.read_bytes()) == manifest[name]["L" + o]["md5"]
             r = subprocess.run([api.CLI, "-d", str(res), str(back)], capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
             assert back.read_bytes() == open(src, "rb").read()
@@ -201,3 +202,50 @@ def test_16384_photo_rgba_matches_reference_md5_and_roundtrips(gpu, manifest):
     torch.cuda.synchronize()
     assert torch.equal(d_out[: W * H * 4].view(H, W, 4), d_r)
     ctx.close()
+
+
+def test_batched_launch_equals_single_image_launches(gpu, po):
+    """One batched launch over B different rasters produces, per image, exactly the bytes of a single-image launch."""
+    import torch
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import synth_raster
+    W, H, B = 900, 700, 3
+    rs = [synth_raster("photo", W, H, True, seed=s + 1) for s in range(B)]
+    ctx = gpu.Context(W, H, 4, batch=B)
+    d_r = [torch.from_numpy(r).cuda() for r in rs]
+    d_b = [torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    lens = ctx.encode_device_batch(1, [t.data_ptr() for t in d_r], [t.data_ptr() for t in d_b])
+    blobs = [d_b[i][:lens[i]].cpu().numpy().tobytes() for i in range(B)]
+    for i in range(B):
+        assert blobs[i] == po.encode_tiles(1, rs[i]), i
+    offs = [walk_tile_offsets(b, ctx.n_tiles)[0] for b in blobs]
+    d_o = [torch.zeros(W * H * 4 + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    ctx.decode_device_batch(1, [t.data_ptr() for t in d_b], offs, [t.data_ptr() for t in d_o])
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert np.array_equal(d_o[i][: W * H * 4].cpu().numpy().reshape(H, W, 4), rs[i]), i
+    ctx.close()
+
+
+def test_mode2_device_entry_points_match_oracle(gpu, po):
+    """Mode 2 (RGB) through the device-resident C-ABI: colour, gray, single-colour and raw tiles in one raster."""
+    import torch
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import special_cases
+    for name, raster in special_cases():
+        raster = np.ascontiguousarray(po.normalize_rgba(raster))
+        if raster.shape[2] != 3:
+            continue
+        h, w, _ = raster.shape
+        ctx = gpu.Context(w, h, 3)
+        d_r = torch.from_numpy(raster).cuda()
+        d_b = torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        n = ctx.encode_device(2, d_r.data_ptr(), d_b.data_ptr())
+        blobs = d_b[:n].cpu().numpy().tobytes()
+        assert blobs == po.encode_tiles(2, raster), name
+        off, _ = walk_tile_offsets(blobs, ctx.n_tiles)
+        d_o = torch.zeros(h * w * 3 + 64, dtype=torch.uint8, device="cuda")
+        ctx.decode_device(2, d_b.data_ptr(), n, off, d_o.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_o[: h * w * 3].cpu().numpy().reshape(h, w, 3), raster), name
+        ctx.close()

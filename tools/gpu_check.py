@@ -103,6 +103,59 @@ def check_encode(name, raster, max_tiles_detail=3):
     return ok_all
 
 
+def parse_m2_blob(blob):
+    """Split a mode-2 colour tile blob into (type, b-bytes, [17 blocks])."""
+    h0 = int.from_bytes(blob[:4], "little")
+    ty = h0 >> 24
+    if ty in (0, 255) or (ty >> 4) == 2:
+        return ty, blob[4:], []
+    bsz = int.from_bytes(blob[4:8], "little")
+    o = 4 + bsz
+    blocks = []
+    for _ in range(17):
+        sz = int.from_bytes(blob[o:o + 4], "little") & 0xFFFFFF
+        blocks.append(blob[o:o + sz]); o += sz
+    return ty, blob[4:4 + bsz], blocks
+
+
+def check_encode_m2(name, raster):
+    h, w, ch = raster.shape
+    if ch != 3:
+        return True
+    ctx = xpng_amd.Context(w, h, ch)
+    d_r = torch.from_numpy(raster).cuda()
+    d_b = torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    n = ctx.encode_device(2, d_r.data_ptr(), d_b.data_ptr())
+    gpu = d_b[:n].cpu().numpy().tobytes()
+    ref = po.encode_tiles(2, raster)
+    same = gpu == ref
+    say(f"[enc2] {name:33s} {w}x{h}x{ch} tiles={ctx.n_tiles:4d} bytes gpu={len(gpu)} ref={len(ref)} {'OK' if same else 'MISMATCH'}")
+    if not same:
+        ro, _ = walk_tile_offsets(ref, ctx.n_tiles)
+        try:
+            go, _ = walk_tile_offsets(gpu, ctx.n_tiles)
+        except Exception:
+            go = ro
+        for ti in range(ctx.n_tiles):
+            rb = ref[ro[ti]:ro[ti + 1] if ti + 1 < ctx.n_tiles else len(ref)]
+            gb = gpu[go[ti]:go[ti + 1] if ti + 1 < ctx.n_tiles else len(gpu)]
+            if rb == gb:
+                continue
+            say(f"   tile {ti} {ctx.tile(ti)}: gpu hdr={gb[:8].hex()} ({len(gb)}B) ref hdr={rb[:8].hex()} ({len(rb)}B)")
+            try:
+                gt, gbits, gblk = parse_m2_blob(gb); rt, rbits, rblk = parse_m2_blob(rb)
+                if gbits != rbits:
+                    say("      b differs: " + first_diff(np.frombuffer(gbits, np.uint8), np.frombuffer(rbits, np.uint8)))
+                for k, (x, y) in enumerate(zip(gblk, rblk)):
+                    if x != y:
+                        say(f"      block {k}: gpu {len(x)}B {x[:12].hex()} ref {len(y)}B {y[:12].hex()} " + first_diff(np.frombuffer(x, np.uint8), np.frombuffer(y, np.uint8)))
+            except Exception as e:
+                say(f"      (parse failed: {e!r})")
+            break
+    ctx.close()
+    return same
+
+
 def check_decode(name, raster):
     h, w, ch = raster.shape
     blobs = po.encode_tiles(1, raster)
@@ -129,6 +182,32 @@ def check_decode(name, raster):
             if not np.array_equal(sub_o, sub_r):
                 dd = np.argwhere(sub_o != sub_r)
                 say(f"   tile {ti} {t} type=0x{blobs[off[ti]+3]:02x}: {len(dd)} diffs, first (y,x,c)={dd[0].tolist()} chans={np.unique(dd[:,2]).tolist()}")
+                break
+    ctx.close()
+    return same
+
+
+def check_decode_m2(name, raster):
+    h, w, ch = raster.shape
+    if ch != 3:
+        return True
+    blobs = po.encode_tiles(2, raster)
+    ctx = xpng_amd.Context(w, h, ch)
+    off, total = walk_tile_offsets(blobs, ctx.n_tiles)
+    d_b = torch.from_numpy(np.frombuffer(blobs + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+    d_r = torch.zeros(h * w * ch + 64, dtype=torch.uint8, device="cuda")
+    ctx.decode_device(2, d_b.data_ptr(), len(blobs), off, d_r.data_ptr())
+    torch.cuda.synchronize()
+    out = d_r[: h * w * ch].cpu().numpy().reshape(h, w, ch)
+    same = np.array_equal(out, raster)
+    say(f"[dec2] {name:33s} {w}x{h}x{ch} tiles={ctx.n_tiles:4d} {'OK' if same else 'MISMATCH'}")
+    if not same:
+        d = np.argwhere(out != raster)
+        for ti, t in enumerate(ctx.tiles()):
+            so, sr = out[t[1]:t[1] + t[3], t[0]:t[0] + t[2]], raster[t[1]:t[1] + t[3], t[0]:t[0] + t[2]]
+            if not np.array_equal(so, sr):
+                dd = np.argwhere(so != sr)
+                say(f"   tile {ti} {t} type=0x{blobs[off[ti]+3]:02x}: {len(dd)} diffs, first (y,x,c)={dd[0].tolist()} gpu={so[tuple(dd[0][:2])].tolist()} ref={sr[tuple(dd[0][:2])].tolist()}")
                 break
     ctx.close()
     return same
@@ -176,7 +255,8 @@ def main():
     bad = 0
     for name, r in cases(level):
         r = np.ascontiguousarray(r)
-        for fn in ([check_encode] if what == "enc" else [check_decode] if what == "dec" else [check_encode, check_decode]):
+        for fn in ({"enc": [check_encode], "dec": [check_decode], "enc2": [check_encode_m2], "dec2": [check_decode_m2],
+                    "m2": [check_encode_m2, check_decode_m2]}.get(what, [check_encode, check_decode])):
             try:
                 if not fn(name, r):
                     bad += 1

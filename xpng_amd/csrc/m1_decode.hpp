@@ -358,20 +358,14 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ 
 // head) backed by two prefetched 8-byte chunks; a step is v_readlane (head of the current queue -> SGPR), a predicated
 // 8-bit shift on the owning lane, and a scalar pack of the output.  No LDS, no global load on the dependent chain.
 // Output: nl sequence in coded-pixel order.      grid = tiles, block = 64.
-__global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
-                                                 TileSel sel, const uint8_t *__restrict__ ctxsym,
-                                                 uint8_t *__restrict__ nlseq) {
-    const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
-    const DecTile d = info[j];
-    if (d.type == 0) return;
-    const TileDesc t = tiles[vtile(sel, j)];
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ctx_start[9]);
-    const uint8_t *base = ctxsym + t.pbase;  // 256-byte aligned, padded: chunk loads never leave the plane
-    uint8_t *out = nlseq + t.pbase;
+// core of the walk: `base` = 256-byte aligned start of the tile's symbol area, qs = this lane's queue start inside it
+// (lanes 0..8), total = number of symbols to produce.  Single-wave workgroup.
+__device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in, uint32_t total, uint8_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
     // queue supply: every queue is staged through its own 2 KB LDS ring in 1 KB units (coalesced copies by the whole
     // wave, triggered at 8-step block boundaries when a queue's read position nears the end of what is staged).
     __shared__ __align__(16) uint8_t qring[9][2048];
-    const uint32_t qs = lane < 9 ? d.ctx_start[lane] : 0;
+    const uint32_t qs = lane < 9 ? qs_in : 0;
     const uint32_t qsa = qs & ~15u;  // 16-byte aligned start of this lane's queue inside the tile's symbol area
     for (uint32_t c = 0; c < 9; c++) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, (int)c);
@@ -430,6 +424,17 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
         const uint32_t sy = pop();
         if (lane == 0) out[k] = (uint8_t)sy;
     }
+}
+
+__global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
+                                                 TileSel sel, const uint8_t *__restrict__ ctxsym,
+                                                 uint8_t *__restrict__ nlseq) {
+    const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
+    const DecTile d = info[j];
+    if (d.type == 0) return;
+    const TileDesc t = tiles[vtile(sel, j)];
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ctx_start[9]);
+    ctx_walk(ctxsym + t.pbase, lane < 9 ? d.ctx_start[lane] : 0, total, nlseq + t.pbase);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -502,29 +507,13 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ 
 // rows advance as an anti-diagonal wavefront: thread r handles row yb+r and, at step s, column s-r.  Its U is what
 // thread r-1 produced one step earlier (LDS, double-buffered by step parity), its UL is its previous U, its L its own
 // previous output.  Tiles taller than 1024 rows run in bands; a band's first row reads U from the raster.
+// Anti-diagonal wavefront over one tile.  predmode: 0 = average (p2a), 1 = gradient (p3a), 2 = left (p1x), 3 = up (p1y) for
+// interior pixels; row 0 always predicts from the left and column 0 from above.  `first` = the tile's first pixel.
+// rs[i] = packed residual word of pixel i (r | g<<8 | b<<16 | coded<<24); al = alpha plane (RGBA) or unused.
 template <int PXSZ>
-__global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ info,
-                                                    const TileDesc *__restrict__ tiles, TileSel sel,
-                                                    const uint8_t *__restrict__ alpha, const uint32_t *__restrict__ resid,
-                                                    uint8_t *const *__restrict__ rasters, uint64_t bpr) {
-    const uint32_t j = blockIdx.x, tid = threadIdx.x;
-    const DecTile d = info[j];
-    const TileDesc t = tiles[vtile(sel, j)];
-    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
-    if (d.type == 0) {
-        const uint8_t *src = d.blob + 4;
-        const uint64_t row = (uint64_t)t.w * PXSZ;
-        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
-        return;
-    }
-    const int useGrad = (d.type >> 1) & 1;
-    const uint8_t *al = alpha + t.pbase;
-    const uint32_t *rs = resid + t.pbase;
-    __shared__ uint32_t s_row[2][1024];
-    // first pixel from the head of k (libxpng.c:850): bytes MSB-first
-    const uint32_t kw0 = ld32u(d.blob + 8);
-    uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16);
-    if (PXSZ == 4) first |= (kw0 & 255u) << 24;
+__device__ inline void recon_wavefront(const TileDesc &t, uint8_t *__restrict__ dst, uint64_t bpr, const uint8_t *__restrict__ al,
+                                       const uint32_t *__restrict__ rs, uint32_t first, int predmode, uint32_t (*s_row)[1024]) {
+    const uint32_t tid = threadIdx.x;
     for (uint32_t yb = 0; yb < t.h; yb += 1024) {
         const uint32_t rows = (t.h - yb) < 1024u ? (t.h - yb) : 1024u;
         const uint32_t y = yb + tid;
@@ -557,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
                             int pred;
                             if (y == 0) pred = l;
                             else if (x == 0) pred = u;
-                            else pred = useGrad ? pred_grad(l, u, ul) : pred_avg(l, u);
+                            else pred = predmode == 0 ? pred_avg(l, u) : predmode == 1 ? pred_grad(l, u, ul) : predmode == 2 ? l : u;
                             outpx |= (((rw >> (8 * c)) + (uint32_t)pred) & 255u) << (8 * c);
                         }
                     }
@@ -579,15 +568,33 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
     }
 }
 
+template <int PXSZ>
+__global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ info,
+                                                    const TileDesc *__restrict__ tiles, TileSel sel,
+                                                    const uint8_t *__restrict__ alpha, const uint32_t *__restrict__ resid,
+                                                    uint8_t *const *__restrict__ rasters, uint64_t bpr) {
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    const DecTile d = info[j];
+    const TileDesc t = tiles[vtile(sel, j)];
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
+    if (d.type == 0) {
+        const uint8_t *src = d.blob + 4;
+        const uint64_t row = (uint64_t)t.w * PXSZ;
+        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+        return;
+    }
+    __shared__ uint32_t s_row[2][1024];
+    // first pixel from the head of k (libxpng.c:850): bytes MSB-first
+    const uint32_t kw0 = ld32u(d.blob + 8);
+    uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16);
+    if (PXSZ == 4) first |= (kw0 & 255u) << 24;
+    recon_wavefront<PXSZ>(t, dst, bpr, alpha + t.pbase, resid + t.pbase, first, (d.type >> 1) & 1, s_row);
+}
+
 // --------------------------------------------------------------------------------------------------
-// Launch the whole decode of tiles [t0, t1) of every image of the batch.  d_blob_ptrs / d_raster_ptrs are device arrays
-// of B pointers; tile_off holds B * cnt blob offsets (image-major), relative to each image's blob buffer.
-inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
-                            int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
-                            uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr) {
-    const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
-    const TileSel sel{t0, cnt, (uint32_t)n_tiles};
-    const uint64_t plane = plane_total;
+// (re)allocate the decode workspace and bring the tile offsets to the device
+inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane, const uint64_t *tile_off, uint32_t t0,
+                             uint32_t total, hipStream_t s, std::string &err) {
     auto bad = [&](const char *m) { err = m; return 1; };
     if (ws.cap_tiles < (uint64_t)B * n_tiles || ws.cap_plane < plane) {
         decode_ws_free(ws);
@@ -605,6 +612,19 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         ws.last_off.assign(tile_off, tile_off + total);
         ws.last_t0 = t0;
     }
+    return 0;
+}
+
+// Launch the whole decode of tiles [t0, t1) of every image of the batch.  d_blob_ptrs / d_raster_ptrs are device arrays
+// of B pointers; tile_off holds B * cnt blob offsets (image-major), relative to each image's blob buffer.
+inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
+                            int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
+                            uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr) {
+    const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
+    const TileSel sel{t0, cnt, (uint32_t)n_tiles};
+    const uint64_t plane = plane_total;
+    auto bad = [&](const char *m) { err = m; return 1; };
+    if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err)) return 1;
     const uint64_t bpr = W * (uint64_t)pxsz;
     if (!ws.side) {
         if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess ||

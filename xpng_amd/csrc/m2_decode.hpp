@@ -1,0 +1,369 @@
+// m2_decode.hpp -- mode-2 (RGB slow level) tile DECODE kernels for gfx950.
+//
+// Reference path restated: dec_2_th (libxpng.c:929-961) = raw / when_single_color (916-927) / when_grayscale (868-899) /
+// 17x decompress_block (rANS v1, 262-301) + DEC/DEC4 (901-914).  Stages:
+//
+//   k_m2_dec_parse   one thread per tile: tile kind, the 17 (or 1) block headers, and the frequency tables, which sit in the
+//                    shared bit stream `b` in block order and must be read serially (sparse tables have data-dependent length)
+//   k_rans1_decode   one wave per (tile, stream): forwards over the symbols, state0 refills before state1; same hot-symbol
+//                    cache / LDS tables / scalar word cursor as the v2 decoder
+//   ctx_walk         the nl context chain (shared with mode 1)
+//   k_m2_dec_resid   class-stream routing back to pixels (rank by nl via ballots), zig-zag / green add-back
+//   k_m2_dec_recon   fill / raw copy / anti-diagonal wavefront (shared with mode 1); gray tiles use predictor m
+#pragma once
+#include "common.hpp"
+#include "m1_decode.hpp"
+#include "m2_encode.hpp"
+
+namespace xpng {
+
+struct M2DecTile {
+    const uint8_t *blob;
+    uint32_t kind;    // 0 raw colour, 1 colour, 2 gray, 3 raw gray, 4 single colour
+    uint32_t m;       // colour: Y<<1|G ; gray: predictor
+    uint32_t bsz;     // bytes of the b region including its size word
+    uint32_t coded;   // colour: number of context symbols (= n - 1)
+};
+// M2Blk is reused per (tile, slot): type, n, cnt = byte offset of the block inside the blob, pbits = bit offset of its raw
+// symbols in b (type 2) or its single symbol (type 1).
+
+// random-access MSB-first bit read from the words at `w` (bits past `endbit` read as 0, like BITSTREAM_FILL past DP)
+__device__ __forceinline__ uint32_t bits_at(const uint8_t *w, uint64_t pos, uint32_t c, uint64_t endbit) {
+    const uint64_t wi = pos >> 5;
+    const uint32_t a = wi * 32 < endbit ? ld32u(w + wi * 4) : 0u, b = (wi + 1) * 32 < endbit ? ld32u(w + wi * 4 + 4) : 0u;
+    const uint64_t two = ((uint64_t)a << 32) | b;
+    return (uint32_t)((two >> (64 - (pos & 31) - c)) & ((1ull << c) - 1));
+}
+
+__global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off, uint32_t cnt,
+                               uint32_t total, const TileDesc *__restrict__ tiles, TileSel sel, M2DecTile *__restrict__ info,
+                               M2Blk *__restrict__ blk, uint16_t *__restrict__ tabs) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const uint32_t tile = vtile(sel, j);
+    const TileDesc t = tiles[tile];
+    M2DecTile d{};
+    d.blob = blobs[j / cnt] + off[j];
+    const uint32_t h0 = ld32u(d.blob), ty = h0 >> 24;
+    M2Blk *mb = blk + (uint64_t)tile * M2_SLOTS;
+    if (ty == 0) d.kind = 0;
+    else if (ty == 255) d.kind = 4;
+    else if ((ty >> 4) == 2) { d.kind = (ty & 8) ? 3 : 2; d.m = ty & 3; }
+    else { d.kind = 1; d.m = ty & 3; }
+    if (d.kind == 1 || d.kind == 2) {
+        d.bsz = ld32u(d.blob + 4);
+        const uint8_t *bw = d.blob + 8;
+        const uint64_t endbit = (uint64_t)(d.bsz - 4) * 8;
+        uint64_t pos = d.kind == 1 ? 24 : 8;
+        uint32_t o = 4 + d.bsz, coded = 0;
+        const uint32_t s0 = d.kind == 1 ? 0 : 17, s1 = d.kind == 1 ? M2_STREAMS : 18;
+        for (uint32_t s = s0; s < s1; s++) {
+            const uint32_t Nnom = m2_nominal(s), pb = s >= 17 ? 15 : 14, rawBits = (uint32_t)bit_width(Nnom - 1);
+            const uint32_t hdr = ld32u(d.blob + o), type = hdr >> 24, w1 = type ? ld32u(d.blob + o + 4) : 0;
+            M2Blk r{type, 0, o, 0};
+            if (type == 1) { r.n = w1 & 0xFFFFFF; r.pbits = w1 >> 24; }
+            else if (type == 2) { r.n = w1; r.pbits = (uint32_t)pos; pos += (uint64_t)w1 * rawBits; }
+            else if (type == 3 || type == 4) {
+                r.n = w1;
+                uint16_t *F = tabs + ((uint64_t)tile * M2_SLOTS + s) * 256;
+                for (uint32_t i = 0; i < Nnom; i++) {
+                    uint32_t f;
+                    if (type == 3) { f = bits_at(bw, pos, pb, endbit); pos += pb; }
+                    else if (bits_at(bw, pos, 1, endbit)) { f = bits_at(bw, pos + 1, pb, endbit); pos += pb + 1; }
+                    else { f = 0; pos += 1; }
+                    F[i] = (uint16_t)f;
+                }
+            }
+            if (s < 9) coded += r.n;
+            mb[s] = r;
+            o += hdr & 0xFFFFFF;
+        }
+        d.coded = coded;
+    }
+    (void)t;
+    info[j] = d;
+}
+
+// --------------------------------------------------------------------------------------------------
+// one v1 block -> symbols (decompress_block, libxpng.c:262-301).  Single-wave workgroup per (tile, slot).
+template <int MAXPB>
+__global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                     uint32_t s_first, uint32_t s_count, const M2Blk *__restrict__ blk,
+                                                     const uint16_t *__restrict__ tabs, uint8_t *__restrict__ scratch2,
+                                                     const uint64_t *__restrict__ sbase2) {
+    __shared__ uint8_t slot2sym[1 << MAXPB];
+    __shared__ uint32_t fc[256];
+    __shared__ uint32_t wring[512];
+    __shared__ uint8_t oring[512];
+    const uint32_t j = blockIdx.x / s_count, slot = s_first + blockIdx.x % s_count, lane = threadIdx.x & 63, par = lane & 1;
+    const M2DecTile d = info[j];
+    if (!((d.kind == 1 && slot < 17) || (d.kind == 2 && slot == 17))) return;
+    const uint32_t tile = vtile(sel, j);
+    const TileDesc t = tiles[tile];
+    const M2Blk mb = blk[(uint64_t)tile * M2_SLOTS + slot];
+    uint8_t *out = scratch2 + sbase2[tile] + m2_off_stream(t.n, slot);
+    const uint32_t type = sgpr(mb.type), n = sgpr(mb.n);
+    const uint32_t Nnom = m2_nominal(slot);
+    const int pb = slot >= 17 ? 15 : 14;
+    if (type == 0 || n == 0) return;
+    if (type == 1) {
+        for (uint32_t i = lane; i < n; i += 64) out[i] = (uint8_t)mb.pbits;
+        return;
+    }
+    if (type == 2) {  // raw symbols from b (libxpng.c:273)
+        const uint32_t rb = (uint32_t)bit_width(Nnom - 1);
+        const uint8_t *bw = d.blob + 8;
+        const uint64_t endbit = (uint64_t)(d.bsz - 4) * 8;
+        for (uint32_t i = lane; i < n; i += 64) out[i] = (uint8_t)bits_at(bw, (uint64_t)mb.pbits + (uint64_t)i * rb, rb, endbit);
+        return;
+    }
+    if (type != 3 && type != 4) return;
+    const uint8_t *blkp = d.blob + mb.cnt;
+    const uint32_t size = sgpr(ld32u(blkp)) & 0xFFFFFF;
+    if (size < 24) return;  // libxpng.c:285
+    const uint8_t *words = blkp + 24;
+    const uint32_t nw = (size - 24) >> 2;
+    const uint16_t *F16 = tabs + ((uint64_t)tile * M2_SLOTS + slot) * 256;
+    uint32_t hot0, hot1;
+    {   // cum by 4-per-lane partial sums + wave scan; fc[i] = F | cum << 16
+        const uint32_t b = lane * 4;
+        const uint32_t f0 = b + 0 < Nnom ? F16[b + 0] : 0, f1 = b + 1 < Nnom ? F16[b + 1] : 0, f2 = b + 2 < Nnom ? F16[b + 2] : 0, f3 = b + 3 < Nnom ? F16[b + 3] : 0;
+        const uint32_t tot = f0 + f1 + f2 + f3;
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t v = __shfl_up(incl, dd);
+            if ((int)lane >= dd) incl += v;
+        }
+        const uint32_t c0 = incl - tot, c1 = c0 + f0, c2 = c1 + f1, c3 = c2 + f2;
+        if (b + 0 < Nnom) fc[b + 0] = f0 | (c0 << 16);
+        if (b + 1 < Nnom) fc[b + 1] = f1 | (c1 << 16);
+        if (b + 2 < Nnom) fc[b + 2] = f2 | (c2 << 16);
+        if (b + 3 < Nnom) fc[b + 3] = f3 | (c3 << 16);
+        auto wmax = [&](uint32_t v) {
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) { const uint32_t o = __shfl_xor(v, o2); v = o > v ? o : v; }
+            return v;
+        };
+        const uint32_t k0 = (f0 << 8) | (b + 0), k1 = (f1 << 8) | (b + 1), k2 = (f2 << 8) | (b + 2), k3 = (f3 << 8) | (b + 3);
+        uint32_t m = k0 > k1 ? k0 : k1; m = k2 > m ? k2 : m; m = k3 > m ? k3 : m;
+        hot0 = wmax(m);
+        auto ex = [&](uint32_t k) { return k == hot0 ? 0u : k; };
+        uint32_t m2 = ex(k0) > ex(k1) ? ex(k0) : ex(k1); m2 = ex(k2) > m2 ? ex(k2) : m2; m2 = ex(k3) > m2 ? ex(k3) : m2;
+        hot1 = wmax(m2);
+    }
+    __syncthreads();
+    {
+        const uint32_t scale = 1u << pb;
+        for (uint32_t s = lane; s < scale; s += 64) {
+            uint32_t lo = 0, hi = Nnom - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
+            }
+            while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;
+            slot2sym[s] = (uint8_t)lo;
+        }
+    }
+    __syncthreads();
+    const uint32_t sym0 = hot0 & 255u, sym1 = hot1 & 255u;
+    const uint32_t e0 = fc[sym0], e1 = fc[sym1];
+    const uint32_t F0 = e0 & 0xFFFF, C0 = e0 >> 16, F1 = (hot1 >> 8) ? (e1 & 0xFFFF) : 0u, C1 = e1 >> 16;
+    const uint32_t mask = (1u << pb) - 1;
+    uint64_t s = ld64u(blkp + 8 + 8 * par);  // state0 at +8, state1 at +16
+    uint32_t rw = 0;                          // scalar cursor: next word to read is words[rw]
+    uint32_t ring_hi = nw < 512 ? nw : 512;   // ring holds word indices [ring_hi - 512, ring_hi) (those >= 0)
+    for (uint32_t i = lane; i < ring_hi; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
+    __syncthreads();
+    rw = sgpr(rw); ring_hi = sgpr(ring_hi);
+    auto refill = [&]() {
+        if (ring_hi < nw && rw + 128 > ring_hi) {
+            const uint32_t new_hi = ring_hi + 256 < nw ? ring_hi + 256 : nw;
+            __syncthreads();
+            for (uint32_t i = ring_hi + lane; i < new_hi; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
+            ring_hi = new_hi;
+            __syncthreads();
+        }
+    };
+    auto flush = [&](uint32_t base, uint32_t hi) {
+        __syncthreads();
+        for (uint32_t i = base + lane; i < hi; i += 64) out[i] = oring[i & 511u];
+        __syncthreads();
+    };
+    auto decode_one = [&](uint32_t &sym) {
+        const uint32_t slt = (uint32_t)s & mask;
+        const uint32_t d0 = slt - C0, d1 = slt - C1;
+        const bool hit0 = d0 < F0, hit1 = d1 < F1;
+        uint32_t F, offv;
+        if (__ballot(!(hit0 || hit1)) == 0) { F = hit0 ? F0 : F1; offv = hit0 ? d0 : d1; sym = hit0 ? sym0 : sym1; }
+        else { sym = slot2sym[slt]; const uint32_t e = fc[sym]; F = e & 0xFFFF; offv = slt - (e >> 16); }
+        return (uint64_t)F * (s >> pb) + offv;
+    };
+    const uint32_t pairs = sgpr(n >> 1);
+    uint32_t w1 = wring[rw & 511u], w2 = wring[(rw + 1) & 511u];
+    uint32_t flushed = 0;
+    for (uint32_t k = 0; k < pairs; k++) {
+        uint32_t sym = 0;
+        s = decode_one(sym);
+        const bool need = s < RANS_L;
+        const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
+        if (lane < 2) oring[(2 * k + par) & 511u] = (uint8_t)sym;
+        if (m) {  // state0 refills first (libxpng.c:295-296); the cursor stops at the end of the block
+            const uint32_t n0 = m & 1u, n1 = m >> 1;
+            if (need) s = (s << 32) | (par ? (n0 ? w2 : w1) : w1);
+            rw = rw + n0 + n1 < nw ? rw + n0 + n1 : nw;
+            refill();
+            w1 = wring[rw & 511u];
+            w2 = wring[(rw + 1) & 511u];
+        }
+        if (((2 * k + 2) & 511u) == 0) { flush(flushed, 2 * k + 2); flushed = 2 * k + 2; }
+    }
+    if (n & 1) {  // libxpng.c:300
+        uint32_t sym = 0;
+        (void)decode_one(sym);
+        if (lane == 0) oring[(n - 1) & 511u] = (uint8_t)sym;
+    }
+    flush(flushed, n);
+}
+
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_m2_dec_walk(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                    const uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
+                                                    uint8_t *__restrict__ nlseq) {
+    const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
+    const M2DecTile d = info[j];
+    if (d.kind != 1) return;
+    const uint32_t tile = vtile(sel, j);
+    const TileDesc t = tiles[tile];
+    ctx_walk(scratch2 + sbase2[tile], lane < 9 ? (uint32_t)m2_off_stream(t.n, lane) : 0, sgpr(d.coded), nlseq + t.pbase);
+}
+
+// --------------------------------------------------------------------------------------------------
+// residual words per pixel.  colour: class streams by nl (DEC_, libxpng.c:901-910) + green add-back; gray: the single stream.
+__global__ __launch_bounds__(1024) void k_m2_dec_resid(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                       const uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
+                                                       const uint8_t *__restrict__ nlseq, uint32_t *__restrict__ resid) {
+    const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const M2DecTile d = info[j];
+    if (d.kind != 1 && d.kind != 2) return;
+    const uint32_t tile = vtile(sel, j);
+    const TileDesc t = tiles[tile];
+    const uint8_t *sc = scratch2 + sbase2[tile];
+    uint32_t *rs = resid + t.pbase;
+    if (d.kind == 2) {
+        const uint8_t *st = sc + m2_off_stream(t.n, 17);
+        for (uint32_t i = tid; i < t.n; i += 1024) {
+            uint32_t w = 0;
+            if (i) { const uint32_t v = (uint32_t)zz_dec(st[i - 1]) & 255u; w = v | (v << 8) | (v << 16) | (1u << 24); }
+            rs[i] = w;
+        }
+        return;
+    }
+    const uint8_t *nls = nlseq + t.pbase;
+    const int useG = d.m & 1;
+    __shared__ uint32_t s_wave[16][9], s_run[9];
+    if (tid < 9) s_run[tid] = 0;
+    __syncthreads();
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t i0 = 0; i0 < t.n; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        const bool coded = i < t.n && i > 0;
+        const uint32_t nl = coded ? nls[i - 1] : 0;
+        uint32_t rank = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t c = 1; c < 9; c++) {
+            const uint64_t m = __ballot(coded && nl == c);
+            if (nl == c) rank = (uint32_t)__popcll(m & lt);
+            if (lane == c) cnt = (uint32_t)__popcll(m);
+        }
+        if (lane >= 1 && lane < 9) s_wave[wv][lane] = cnt;
+        __syncthreads();
+        if (i < t.n) {
+            uint32_t word = 0;
+            if (coded) {
+                int dr = 0, dg = 0, db = 0;
+                if (nl) {
+                    uint32_t base = s_run[nl];
+                    for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave[w2][nl];
+                    const uint8_t *st = sc + m2_off_stream(t.n, 8 + nl);
+                    const uint32_t k = base + rank;
+                    uint32_t zr, zg, zb;
+                    if (nl == 1) { const uint32_t v = st[k]; zr = v >> 2; zg = (v >> 1) & 1; zb = v & 1; }
+                    else if (nl == 2) { const uint32_t v = st[k]; zr = v >> 4; zg = (v >> 2) & 3; zb = v & 3; }
+                    else { zr = st[3 * k]; zg = st[3 * k + 1]; zb = st[3 * k + 2]; }
+                    dr = zz_dec((int)zr); dg = zz_dec((int)zg); db = zz_dec((int)zb);
+                }
+                const uint32_t y = i / t.w, x = i - y * t.w;
+                if (useG && x > 0 && y > 0) { dr += dg; db += dg; }
+                word = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) | (1u << 24);
+            }
+            rs[i] = word;
+        }
+        uint32_t tot = 0;
+        if (tid >= 1 && tid < 9) for (int w2 = 0; w2 < 16; w2++) tot += s_wave[w2][tid];
+        __syncthreads();
+        if (tid >= 1 && tid < 9) s_run[tid] += tot;
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                       const uint32_t *__restrict__ resid, uint8_t *const *__restrict__ rasters,
+                                                       uint64_t bpr) {
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    const M2DecTile d = info[j];
+    const TileDesc t = tiles[vtile(sel, j)];
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * 3;
+    const uint64_t row = (uint64_t)t.w * 3;
+    if (d.kind == 0) {  // raw rows (libxpng.c:941)
+        const uint8_t *src = d.blob + 4;
+        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+        return;
+    }
+    if (d.kind == 4) {  // single colour (libxpng.c:916-927)
+        const uint8_t *px = d.blob + 4;
+        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = px[o % 3]; }
+        return;
+    }
+    if (d.kind == 3) {  // raw gray (libxpng.c:875-878)
+        const uint8_t *src = d.blob + 4;
+        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[y * t.w + o / 3]; }
+        return;
+    }
+    __shared__ uint32_t s_row[2][1024];
+    const uint32_t w0 = ld32u(d.blob + 8);  // head of b: first pixel, MSB first
+    uint32_t first;
+    int predmode;
+    if (d.kind == 2) {
+        const uint32_t g = w0 >> 24;
+        first = g | (g << 8) | (g << 16);
+        predmode = d.m == 0 ? 2 : d.m == 1 ? 3 : d.m == 2 ? 0 : 1;  // p1x, p1y, p2a, p3a (libxpng.c:890-895)
+    } else {
+        first = ((w0 >> 24) & 255u) | (((w0 >> 16) & 255u) << 8) | (((w0 >> 8) & 255u) << 16);
+        predmode = (d.m >> 1) & 1;
+    }
+    recon_wavefront<3>(t, dst, bpr, nullptr, resid + t.pbase, first, predmode, s_row);
+}
+
+// Launch the mode-2 decode of tiles [t0, t1) of every image of the batch (RGB only).
+inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
+                            const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
+                            uint8_t *const *d_raster_ptrs, M2DecTile *d_info2, M2Blk *d_blk2, uint16_t *d_tabs2, uint8_t *d_scratch2,
+                            const uint64_t *d_sbase2, hipStream_t s, std::string &err) {
+    const uint32_t cnt = t1 - t0, total = B * cnt;
+    const TileSel sel{t0, cnt, (uint32_t)n_tiles};
+    if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err)) return 1;
+    const uint64_t bpr = W * 3;
+    if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }
+    k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2);
+    k_rans1_decode<14><<<total * M2_STREAMS, 64, 0, s>>>(d_info2, d_tiles, sel, 0, M2_STREAMS, d_blk2, d_tabs2, d_scratch2, d_sbase2);
+    k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
+    k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);
+    k_m2_dec_resid<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
+    k_m2_dec_recon<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr);
+    if (hipGetLastError() != hipSuccess) { err = "mode-2 decode kernel launch failed"; return 1; }
+    return 0;
+}
+
+}  // namespace xpng

@@ -1,0 +1,481 @@
+// m2_encode.hpp -- mode-2 (XPNG_COMPRESSION_TYPE_SLOW, RGB only) tile ENCODE kernels for gfx950.
+//
+// Reference path restated: enc_2_th (libxpng.c:645-686) = is_single_color (628-643) + is_grayscale (583-626) + pp_rgbx +
+// ENC/ENC4 (33-44) + 17x compress_block (rANS v1, 160-260) + tile container.  Stages:
+//
+//   k_m2_classify   per tile: "all pixels equal the first" / "every pixel has R == G == B" (two OR-reductions)
+//   k_chooser + k_m1_transform_generic<3>   the same predictor chooser and per-pixel arithmetic as mode 1 (ENC == M1ENC for RGB)
+//   k_m2_streams    routing: nl -> context stream cx[pl] (as mode 1) AND residuals -> magnitude-class stream st[nl]
+//                   (nl=1: one 3-bit symbol, nl=2: one 6-bit symbol, nl>=3: three symbols), all by wave ballots
+//   k_m2_gray_syms  gray tiles only: the four candidate predictor streams (p1x, p1y, p2a, p3a)
+//   k_rans1_encode  one wave per (tile, stream): rANS v1 = backwards over the symbols, state1 spills before state0, words are
+//                   emitted in encode order and reversed at gather time; freq table (or the raw symbols) go to the tile's
+//                   shared bit stream `b` as a "piece"
+//   k_m2_select     tile type, gray candidate choice (first minimum), sizes, raw fallbacks
+//   k_m2_bits       wave-parallel splice of the pieces into `b` at arbitrary bit offsets
+//   k_tile_offsets + k_m2_gather   per-image scan and final placement
+#pragma once
+#include "common.hpp"
+#include "m1_encode.hpp"
+#include "rans2.hpp"
+#include "tile_container.hpp"
+
+namespace xpng {
+
+constexpr uint32_t M2_STREAMS = 17, M2_SLOTS = 21;  // 9 context + 8 class streams; +4 gray candidates
+__host__ __device__ inline uint32_t m2_nominal(uint32_t s) {  // alphabet of stream s (libxpng.c:668-669)
+    if (s < 9) return 9;
+    if (s >= 17) return 256;
+    const uint32_t v = s - 8;  // class 1..8
+    return v < 3 ? (1u << (3 * v)) : (1u << v);
+}
+// per-tile scratch layout for mode 2 (bytes, relative to the tile's m2 scratch base)
+__host__ __device__ inline uint64_t m2_small(uint32_t n) { return rup((uint64_t)n + 64, 256); }       // ctx / class 1,2 / gray streams
+__host__ __device__ inline uint64_t m2_big(uint32_t n) { return rup(3ull * n + 64, 256); }            // class >= 3 streams
+__host__ __device__ inline uint64_t m2_off_stream(uint32_t n, uint32_t s) {
+    if (s < 11) return (uint64_t)s * m2_small(n);                                   // ctx 0..8, class 1, 2
+    if (s < 17) return 11 * m2_small(n) + (uint64_t)(s - 11) * m2_big(n);           // class 3..8
+    return 11 * m2_small(n) + (uint64_t)(s - 17) * m2_small(n);                     // gray candidates overlay class >= 3
+}
+__host__ __device__ inline uint64_t m2_blk_cap(uint32_t n, uint32_t s) {  // emitted words (<= 15 bits / symbol) + slack
+    const uint64_t syms = (s >= 11 && s < 17) ? 3ull * n : n;
+    return rup(2 * syms + 512, 256);
+}
+__host__ __device__ inline uint64_t m2_off_blk(uint32_t n, uint32_t s) {
+    uint64_t o = 11 * m2_small(n) + 6 * m2_big(n);
+    if (s >= 17) { o += 11 * m2_blk_cap(n, 0); return o + (uint64_t)(s - 17) * m2_blk_cap(n, 17); }  // gray overlay class >= 3 blocks
+    for (uint32_t k = 0; k < s; k++) o += m2_blk_cap(n, k);
+    return o;
+}
+__host__ __device__ inline uint64_t m2_off_piece(uint32_t n, uint32_t s) {  // table bits of stream s: <= 256 * 16 bits
+    return m2_off_blk(n, 16) + m2_blk_cap(n, 16) + (uint64_t)s * 640;
+}
+__host__ __device__ inline uint64_t m2_off_bits(uint32_t n) { return m2_off_piece(n, M2_SLOTS); }
+__host__ __device__ inline uint64_t m2_bits_cap(uint32_t n) { return rup(3ull * n + 21 * 640 + 256, 256); }
+__host__ __device__ inline uint64_t m2_tile_scratch(uint32_t n) { return m2_off_bits(n) + m2_bits_cap(n); }
+
+struct M2Blk { uint32_t type, n, cnt, pbits; };  // per (tile, slot): block type 0..4, symbols, emitted words, piece bits
+struct M2Tile {                                   // per tile, filled by k_m2_select
+    uint32_t kind;     // 0 raw colour, 1 colour, 2 gray, 3 raw gray, 4 single colour
+    uint32_t m;        // gray: chosen predictor
+    uint32_t bbits;    // total bits of b (head + pieces)
+    uint32_t size;     // blob bytes
+};
+constexpr uint32_t M2F_NOT_SINGLE = 1, M2F_NOT_GRAY = 2;
+
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_m2_classify(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                     const TileDesc *__restrict__ tiles, TileSel sel, uint32_t strips,
+                                                     uint32_t *__restrict__ flags) {
+    const uint32_t tile = vtile(sel, blockIdx.x / strips), strip = blockIdx.x % strips;
+    const TileDesc t = tiles[tile];
+    const uint8_t *raster = rasters[t.img];
+    const uint8_t *base = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * 3;
+    const uint32_t first = load_px<3>(base);
+    const uint32_t i0 = (uint32_t)((uint64_t)t.n * strip / strips), i1 = (uint32_t)((uint64_t)t.n * (strip + 1) / strips);
+    uint32_t f = 0;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const uint32_t y = i / t.w, x = i - y * t.w;
+        const uint32_t p = load_px<3>(base + (uint64_t)y * bpr + (uint64_t)x * 3);
+        if (p != first) f |= M2F_NOT_SINGLE;
+        if (((p >> 8) & 0xFFFF) != (p & 0xFFFF)) f |= M2F_NOT_GRAY;  // g,b == r,g  <=>  r == g == b
+    }
+    const uint64_t a = __ballot(f & 1), b = __ballot(f & 2);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = (a ? M2F_NOT_SINGLE : 0u) | (b ? M2F_NOT_GRAY : 0u);
+        if (w) atomicOr(&flags[tile], w);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// routing for colour tiles: context streams by pl (as k_m1_streams) and class streams by nl.  grid = tiles, block = 1024.
+__global__ __launch_bounds__(1024) void k_m2_streams(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
+                                                     const uint8_t *__restrict__ planes, uint64_t plane_stride,
+                                                     uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
+                                                     uint32_t *__restrict__ stream_n) {
+    const uint32_t tile = vtile(sel, blockIdx.x);
+    const TileDesc t = tiles[tile];
+    if ((flags[tile] & (M2F_NOT_SINGLE | M2F_NOT_GRAY)) != (M2F_NOT_SINGLE | M2F_NOT_GRAY)) return;  // single colour or gray
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t *pnl = planes + t.pbase, *pr_ = planes + plane_stride + t.pbase;
+    const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;
+    uint8_t *sc = scratch2 + sbase2[tile];
+    __shared__ uint32_t s_run_ctx[9], s_run_cls[9];
+    __shared__ uint32_t s_wave_ctx[16][9], s_wave_cls[16][9];
+    __shared__ uint32_t s_wave_last[16];
+    if (tid < 9) { s_run_ctx[tid] = 0; s_run_cls[tid] = 0; }
+    __syncthreads();
+    uint32_t run_pl = 0;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t i0 = 0; i0 < t.n; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        const uint32_t nlv = i < t.n ? pnl[i] : NL_NONE;
+        const bool coded = nlv != NL_NONE;
+        const uint64_t mask = __ballot(coded), lower = mask & lt;
+        const uint32_t wave_last = __shfl(nlv, mask ? 63 - __clzll((long long)mask) : 0);
+        if (lane == 0) s_wave_last[wv] = mask ? wave_last : NL_NONE;
+        const uint32_t prev_in_wave = __shfl(nlv, lower ? 63 - __clzll((long long)lower) : 0);
+        // class rank inside the wave (by nl); class v >= 3 holds 3 symbols per pixel
+        uint32_t cls_rank = 0, cls_cnt = 0;
+#pragma unroll
+        for (uint32_t c = 1; c < 9; c++) {
+            const uint64_t m = __ballot(coded && nlv == c);
+            if (nlv == c) cls_rank = (uint32_t)__popcll(m & lt);
+            if (lane == c) cls_cnt = (uint32_t)__popcll(m);
+        }
+        if (lane >= 1 && lane < 9) s_wave_cls[wv][lane] = cls_cnt;
+        __syncthreads();  // (A)
+        uint32_t carry = run_pl, new_run_pl = run_pl;
+        for (int w2 = 0; w2 < 16; w2++) {
+            const uint32_t wl = s_wave_last[w2];
+            if (w2 < (int)wv && wl != NL_NONE) carry = wl;
+            if (wl != NL_NONE) new_run_pl = wl;
+        }
+        const uint32_t pl = lower ? prev_in_wave : carry;
+        uint32_t ctx_rank = 0, ctx_cnt = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 9; c++) {
+            const uint64_t m = __ballot(coded && pl == c);
+            if (pl == c) ctx_rank = (uint32_t)__popcll(m & lt);
+            if (lane == c) ctx_cnt = (uint32_t)__popcll(m);
+        }
+        if (lane < 9) s_wave_ctx[wv][lane] = ctx_cnt;
+        __syncthreads();  // (B)
+        if (coded) {
+            uint32_t base = s_run_ctx[pl];
+            for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave_ctx[w2][pl];
+            sc[m2_off_stream(t.n, pl) + base + ctx_rank] = (uint8_t)nlv;
+            if (nlv) {
+                uint32_t cb = s_run_cls[nlv];
+                for (uint32_t w2 = 0; w2 < wv; w2++) cb += s_wave_cls[w2][nlv];
+                uint8_t *dst = sc + m2_off_stream(t.n, 8 + nlv);
+                const uint32_t zr = pr_[i], zg = pg[i], zb = pb[i];
+                if (nlv == 1) dst[cb + cls_rank] = (uint8_t)((zr << 2) | (zg << 1) | zb);        // libxpng.c:37
+                else if (nlv == 2) dst[cb + cls_rank] = (uint8_t)((zr << 4) | (zg << 2) | zb);   // libxpng.c:38
+                else { uint8_t *q = dst + 3 * (cb + cls_rank); q[0] = (uint8_t)zr; q[1] = (uint8_t)zg; q[2] = (uint8_t)zb; }  // :39
+            }
+        }
+        uint32_t tot_ctx = 0, tot_cls = 0;
+        if (tid < 9) for (int w2 = 0; w2 < 16; w2++) { tot_ctx += s_wave_ctx[w2][tid]; if (tid) tot_cls += s_wave_cls[w2][tid]; }
+        __syncthreads();  // (C)
+        if (tid < 9) { s_run_ctx[tid] += tot_ctx; s_run_cls[tid] += tot_cls; }
+        run_pl = new_run_pl;
+        __syncthreads();
+    }
+    if (tid < 9) stream_n[(uint64_t)tile * M2_SLOTS + tid] = s_run_ctx[tid];
+    if (tid >= 1 && tid < 9) stream_n[(uint64_t)tile * M2_SLOTS + 8 + tid] = s_run_cls[tid] * (tid >= 3 ? 3u : 1u);
+}
+
+// --------------------------------------------------------------------------------------------------
+// gray tiles: the four candidate symbol streams (libxpng.c:597-604).  grid = tiles * blocks_per_tile, block = 256.
+__global__ __launch_bounds__(256) void k_m2_gray_syms(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                      const TileDesc *__restrict__ tiles, TileSel sel, uint32_t bpt,
+                                                      const uint32_t *__restrict__ flags, uint8_t *__restrict__ scratch2,
+                                                      const uint64_t *__restrict__ sbase2, uint32_t *__restrict__ stream_n) {
+    const uint32_t tile = vtile(sel, blockIdx.x / bpt), chunk = blockIdx.x % bpt;
+    const TileDesc t = tiles[tile];
+    const uint32_t f = flags[tile];
+    if (!(f & M2F_NOT_SINGLE) || (f & M2F_NOT_GRAY)) return;  // only gray, not single-colour, tiles
+    const uint8_t *raster = rasters[t.img];
+    uint8_t *sc = scratch2 + sbase2[tile];
+    if (chunk == 0 && threadIdx.x < 4) stream_n[(uint64_t)tile * M2_SLOTS + 17 + threadIdx.x] = t.n - 1;
+    const uint32_t i = chunk * 256 + threadIdx.x + 1;  // pixel 1..n-1 -> symbol i-1
+    if (i >= t.n) return;
+    const uint32_t y = i / t.w, x = i - y * t.w;
+    const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * 3;
+    const int v = p[0];
+    int s0, s1, s2, s3;
+    if (y == 0) s0 = s1 = s2 = s3 = zz_enc(v - p[-3]);
+    else if (x == 0) s0 = s1 = s2 = s3 = zz_enc(v - *(p - bpr));
+    else {
+        const int L = p[-3], U = *(p - bpr), UL = *(p - bpr - 3);
+        s0 = zz_enc(v - L); s1 = zz_enc(v - U); s2 = zz_enc(v - pred_avg(L, U)); s3 = zz_enc(v - pred_grad(L, U, UL));
+    }
+    sc[m2_off_stream(t.n, 17) + i - 1] = (uint8_t)s0;
+    sc[m2_off_stream(t.n, 18) + i - 1] = (uint8_t)s1;
+    sc[m2_off_stream(t.n, 19) + i - 1] = (uint8_t)s2;
+    sc[m2_off_stream(t.n, 20) + i - 1] = (uint8_t)s3;
+}
+
+// --------------------------------------------------------------------------------------------------
+// rANS v1 block (compress_block, libxpng.c:160-260).  One wave per (tile, slot).  The block slot receives
+// [state0 lo,hi][state1 lo,hi][words in EMISSION order]; k_m2_gather writes the final block with the words reversed.
+__global__ __launch_bounds__(64) void k_rans1_encode(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
+                                                     uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
+                                                     const uint32_t *__restrict__ stream_n, M2Blk *__restrict__ blk) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t cum[260];
+    __shared__ EncSym tab[256];
+    __shared__ uint32_t ring[512];
+    __shared__ __align__(16) uint8_t sring[2048];
+    const uint32_t tile = vtile(sel, blockIdx.x / M2_SLOTS), slot = blockIdx.x % M2_SLOTS, lane = threadIdx.x & 63, par = lane & 1;
+    const TileDesc t = tiles[tile];
+    const uint32_t f = flags[tile];
+    const bool single = !(f & M2F_NOT_SINGLE), gray = !single && !(f & M2F_NOT_GRAY);
+    if (single || (gray != (slot >= 17))) return;  // colour tiles run slots 0..16, gray tiles 17..20
+    uint8_t *sc = scratch2 + sbase2[tile];
+    const uint8_t *in = sc + m2_off_stream(t.n, slot);
+    const uint32_t n = sgpr(stream_n[(uint64_t)tile * M2_SLOTS + slot]);
+    const uint32_t Nnom = m2_nominal(slot);
+    const int pb = slot >= 17 ? 15 : 14;
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t.n, slot));
+    M2Blk *mb = blk + (uint64_t)tile * M2_SLOTS + slot;
+    if (n == 0) {  // libxpng.c:167
+        if (lane == 0) *mb = M2Blk{0, 0, 0, 0};
+        return;
+    }
+    rans_histogram(in, n, hist);
+    uint32_t top, distinct;
+    rans_alphabet(hist, Nnom, top, distinct);
+    if (distinct == 1) {  // libxpng.c:169-172: the block carries the symbol
+        if (lane == 0) *mb = M2Blk{1, n, (uint32_t)in[n - 1], 0};
+        return;
+    }
+    const uint32_t N = top + 1;
+    rans_tables(hist, cum, tab, N, n, pb);
+    // ---- recurrence, backwards (libxpng.c:215-243).  even lanes: state0 / even symbol indices; odd lanes: state1.
+    const uint32_t cmpl_base = 1u << pb;
+    const int thr_shift = 31 - pb;
+    uint64_t s = RANS_L;
+    uint32_t cnt = 0, flushed = 0;
+    uint32_t *w = out + 4;
+    const uint8_t *inA = reinterpret_cast<const uint8_t *>((uintptr_t)in & ~(uintptr_t)15);
+    const uint32_t p0 = sgpr((uint32_t)((uintptr_t)in & 15));
+    const uint4 *src = reinterpret_cast<const uint4 *>(inA) + lane;
+    int32_t lo_unit = (int32_t)sgpr((p0 + n - 1) >> 10);  // lowest unit staged; units lo_unit and lo_unit+1 (if it exists) are in the ring
+    reinterpret_cast<uint4 *>(sring)[(lo_unit & 1) * 64 + lane] = src[lo_unit * 64];
+    if (lo_unit > 0) { lo_unit--; reinterpret_cast<uint4 *>(sring)[(lo_unit & 1) * 64 + lane] = src[lo_unit * 64]; }
+    uint4 pre = lo_unit > 0 ? src[(lo_unit - 1) * 64] : make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    auto put = [&](const EncSym &e) {
+        const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
+        const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
+        const uint64_t q = __umul64hi(s, rcp) >> rsh;
+        s += e.bias + q * (uint64_t)(cmpl_base - freq);
+    };
+    const uint32_t pairs = sgpr(n >> 1);
+    if (n & 1) { if (!par) put(tab[in[n - 1]]); }  // libxpng.c:218-225: no spill test on the odd tail
+    int32_t pos = (int32_t)(p0 + 2 * pairs) - 2;  // ring position of the even symbol of the next pair (uniform); may run below p0
+    auto next_sym = [&]() -> uint32_t {
+        if (lo_unit > 0 && pos < lo_unit * 1024 + 8) {  // uniform: rotate the prefetched lower unit in
+            __syncthreads();
+            lo_unit--;
+            reinterpret_cast<uint4 *>(sring)[(lo_unit & 1) * 64 + lane] = pre;
+            if (lo_unit > 0) pre = src[(lo_unit - 1) * 64];
+            __syncthreads();
+        }
+        const uint32_t sy = sring[(uint32_t)(pos + (int32_t)par) & 2047u];
+        pos -= 2;
+        return sy;
+    };
+    auto step = [&](const EncSym &e) {
+        const uint32_t freq = e.freq_shift & 0xFFFF;
+        const bool emit = (uint32_t)(s >> 32) >= (freq << thr_shift);
+        const uint32_t m = sgpr((uint32_t)__ballot(emit) & 3u);  // bit1: state1 spills (first), bit0: state0
+        const uint32_t e1 = m >> 1;
+        if (emit) {
+            if (lane < 2) ring[(cnt + (par ? 0u : e1)) & 511u] = (uint32_t)s;
+            s >>= 32;
+        }
+        cnt += e1 + (m & 1u);
+        put(e);
+        if (cnt - flushed >= 256) {  // uniform
+            __syncthreads();
+            for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
+            flushed += 256;
+            __syncthreads();
+        }
+    };
+    {
+        EncSym ea = tab[next_sym()], eb = tab[next_sym()], ec = tab[next_sym()];
+        uint32_t k = 0;
+        for (; k + 3 <= pairs; k += 3) {
+            step(ea); ea = tab[next_sym()];
+            step(eb); eb = tab[next_sym()];
+            step(ec); ec = tab[next_sym()];
+        }
+        if (k < pairs) { step(ea); ea = eb; k++; }
+        if (k < pairs) { step(ea); k++; }
+    }
+    __syncthreads();
+    for (uint32_t i = flushed + lane; i < cnt; i += 64) w[i] = ring[i & 511u];
+    if (lane < 2) { out[2 * lane] = (uint32_t)s; out[2 * lane + 1] = (uint32_t)(s >> 32); }  // state0 then state1 (libxpng.c:245)
+    // ---- type decision and the table piece (libxpng.c:247-259)
+    const uint32_t rawBits = (uint32_t)bit_width(Nnom - 1);
+    uint32_t tabBits = (Nnom - distinct) + distinct * ((uint32_t)pb + 1);
+    const bool sparse = tabBits < Nnom * (uint32_t)pb;
+    if (!sparse) tabBits = Nnom * (uint32_t)pb;
+    const uint64_t ransBytes = 16 + 4ull * cnt;
+    if ((uint64_t)tabBits + 8 * ransBytes >= (uint64_t)rawBits * n) {
+        if (lane == 0) *mb = M2Blk{2, n, 0, rawBits * n};  // raw symbols travel in b
+        return;
+    }
+    if (lane == 0) {
+        BitW tb{0, 0, reinterpret_cast<uint32_t *>(sc + m2_off_piece(t.n, slot))};
+        for (uint32_t k = 0; k < Nnom; k++) {
+            const uint32_t F = k < N ? hist[k] : 0;
+            if (!sparse) tb.put((uint32_t)pb, F);
+            else if (F) tb.put((uint32_t)pb + 1, F + (1u << pb));
+            else tb.put(1, 0);
+        }
+        tb.finish();
+        *tb.p = 0;
+        *mb = M2Blk{3u + (sparse ? 1u : 0u), n, cnt, tabBits};
+    }
+}
+
+__device__ __forceinline__ uint32_t m2_blk_bytes(const M2Blk &b) {  // final block size
+    return b.type == 0 ? 4u : (b.type <= 2 ? 8u : 24u + 4u * b.cnt);
+}
+
+// --------------------------------------------------------------------------------------------------
+// tile kind, gray choice, sizes.  One thread per tile.
+__global__ void k_m2_select(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total, const uint32_t *__restrict__ flags,
+                            const M2Blk *__restrict__ blk, M2Tile *__restrict__ mt, uint32_t *__restrict__ tile_sz) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const uint32_t tile = vtile(sel, j);
+    const TileDesc t = tiles[tile];
+    const uint32_t f = flags[tile];
+    const M2Blk *b = blk + (uint64_t)tile * M2_SLOTS;
+    M2Tile r{};
+    if (!(f & M2F_NOT_SINGLE)) { r.kind = 4; r.size = 8; }
+    else if (!(f & M2F_NOT_GRAY)) {
+        uint64_t bestB = 1000000, bestR = 1000000;  // libxpng.c:606
+        for (uint32_t m = 0; m < 4; m++) {
+            const uint64_t bsz = 4 + 4ull * ((8 + b[17 + m].pbits + 31) >> 5), rsz = m2_blk_bytes(b[17 + m]);
+            if (bsz + rsz < bestB + bestR) { r.m = m; bestB = bsz; bestR = rsz; }
+        }
+        if (bestB + bestR >= t.n) { r.kind = 3; r.size = t.n + 4; }
+        else { r.kind = 2; r.bbits = 8 + b[17 + r.m].pbits; r.size = (uint32_t)(bestB + bestR + 4); }
+    } else {
+        uint64_t bits = 24, rsz = 0;
+        for (uint32_t s = 0; s < M2_STREAMS; s++) { bits += b[s].pbits; rsz += m2_blk_bytes(b[s]); }
+        const uint64_t bsz = 4 + 4 * ((bits + 31) >> 5);
+        if (bsz + rsz >= 3ull * t.n) { r.kind = 0; r.size = 3 * t.n + 4; }  // libxpng.c:675
+        else { r.kind = 1; r.bbits = (uint32_t)bits; r.size = (uint32_t)(bsz + rsz + 4); }
+    }
+    mt[tile] = r;
+    tile_sz[j] = r.size;
+}
+
+// --------------------------------------------------------------------------------------------------
+// shared bit stream b: head (first pixel) + pieces at arbitrary bit offsets.  One thread per output word.
+// grid = tiles, block = 256.
+__global__ __launch_bounds__(256) void k_m2_bits(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                 const TileDesc *__restrict__ tiles, TileSel sel, const M2Tile *__restrict__ mt,
+                                                 const M2Blk *__restrict__ blk, uint8_t *__restrict__ scratch2,
+                                                 const uint64_t *__restrict__ sbase2) {
+    const uint32_t tile = vtile(sel, blockIdx.x);
+    const TileDesc t = tiles[tile];
+    const M2Tile r = mt[tile];
+    if (r.kind != 1 && r.kind != 2) return;
+    const uint8_t *p0 = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * 3;
+    uint8_t *sc = scratch2 + sbase2[tile];
+    const M2Blk *b = blk + (uint64_t)tile * M2_SLOTS;
+    __shared__ uint32_t s_off[19], s_slot[18];
+    __shared__ uint32_t s_np;
+    if (threadIdx.x == 0) {
+        uint32_t o, np = 0;
+        if (r.kind == 2) { o = 8; s_off[0] = o; s_slot[0] = 17 + r.m; o += b[17 + r.m].pbits; np = 1; }
+        else { o = 24; for (uint32_t s = 0; s < M2_STREAMS; s++) { s_off[np] = o; s_slot[np] = s; o += b[s].pbits; np++; } }
+        s_off[np] = o;
+        s_np = np;
+    }
+    __syncthreads();
+    const uint32_t np = s_np, words = (r.bbits + 31) >> 5;
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_bits(t.n));
+    const uint32_t head = r.kind == 2 ? ((uint32_t)p0[0] << 24) : (((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8));
+    for (uint32_t wi = threadIdx.x; wi < words; wi += 256) {
+        const uint32_t w0 = wi * 32, w1 = w0 + 32;
+        uint32_t val = wi == 0 ? head : 0u;
+        for (uint32_t k = 0; k < np; k++) {
+            const uint32_t o0 = s_off[k], o1 = s_off[k + 1];
+            if (o1 <= w0 || o0 >= w1 || o0 == o1) continue;
+            const uint32_t a = o0 > w0 ? o0 : w0, e = o1 < w1 ? o1 : w1;  // overlap [a, e) in stream bits
+            const uint32_t slot = s_slot[k];
+            const M2Blk mb = b[slot];
+            if (mb.type == 2) {  // raw symbols, rawBits each, MSB first (libxpng.c:251)
+                const uint32_t rb = mb.pbits / mb.n;
+                const uint8_t *st = sc + m2_off_stream(t.n, slot);
+                uint32_t jsym = (a - o0) / rb;
+                for (;; jsym++) {
+                    const uint32_t s0 = o0 + jsym * rb, s1 = s0 + rb;  // this symbol's bits in the stream
+                    if (s0 >= e) break;
+                    const uint32_t lo = s0 > a ? s0 : a, hi = s1 < e ? s1 : e;
+                    const uint32_t v = ((uint32_t)st[jsym] >> (s1 - hi)) & ((1u << (hi - lo)) - 1);
+                    val |= v << (w1 - hi);
+                }
+            } else {  // frequency table bits from the piece buffer (bit 0 = MSB of its word 0)
+                const uint32_t *pw = reinterpret_cast<const uint32_t *>(sc + m2_off_piece(t.n, slot));
+                const uint32_t rel = a - o0, c = e - a;
+                const uint64_t two = ((uint64_t)pw[rel >> 5] << 32) | pw[(rel >> 5) + 1];
+                const uint32_t v = (uint32_t)((two >> (64 - (rel & 31) - c)) & (c == 32 ? 0xFFFFFFFFull : ((1ull << c) - 1)));
+                val |= c == 32 ? v : (v << (w1 - e));
+            }
+        }
+        out[wi] = val;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// final placement.  grid = tiles, block = 256.
+__device__ inline void m2_write_block(uint8_t *dst, const M2Blk &mb, const uint32_t *slotw) {
+    auto w32 = [&](uint32_t byteoff, uint32_t v) { for (int k = 0; k < 4; k++) dst[byteoff + k] = (uint8_t)(v >> (8 * k)); };
+    if (mb.type == 0) { if (threadIdx.x == 0) w32(0, 4); return; }
+    if (mb.type == 1) { if (threadIdx.x == 0) { w32(0, 8u | (1u << 24)); w32(4, mb.n + (mb.cnt << 24)); } return; }
+    if (mb.type == 2) { if (threadIdx.x == 0) { w32(0, 8u | (2u << 24)); w32(4, mb.n); } return; }
+    if (threadIdx.x == 0) { w32(0, (24u + 4u * mb.cnt) | (mb.type << 24)); w32(4, mb.n); }
+    for (uint32_t i = threadIdx.x; i < 4 + mb.cnt; i += blockDim.x)  // states, then the words in reverse emission order
+        w32(8 + 4 * i, i < 4 ? slotw[i] : slotw[4 + (mb.cnt - 1 - (i - 4))]);
+}
+
+__global__ __launch_bounds__(256) void k_m2_gather(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                   const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ sums,
+                                                   const M2Tile *__restrict__ mt, const M2Blk *__restrict__ blk,
+                                                   const uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
+                                                   const uint64_t *__restrict__ off, uint8_t *const *__restrict__ blobs) {
+    const uint32_t j = blockIdx.x, tile = vtile(sel, j);
+    const TileDesc t = tiles[tile];
+    const M2Tile r = mt[tile];
+    const uint8_t *raster = rasters[t.img];
+    const uint8_t *src = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * 3;
+    uint8_t *dst = blobs[t.img] + off[(uint64_t)(j / sel.cnt) * (sel.cnt + 1) + j % sel.cnt];
+    const uint8_t *sc = scratch2 + sbase2[tile];
+    const M2Blk *b = blk + (uint64_t)tile * M2_SLOTS;
+    auto w32 = [&](uint32_t byteoff, uint32_t v) { for (int k = 0; k < 4; k++) dst[byteoff + k] = (uint8_t)(v >> (8 * k)); };
+    if (r.kind == 4) {  // single colour (libxpng.c:637-640)
+        if (threadIdx.x == 0) { w32(0, (255u << 24) | 8u); dst[4] = src[0]; dst[5] = src[1]; dst[6] = src[2]; dst[7] = 0; }
+        return;
+    }
+    if (r.kind == 0) {  // raw rows (libxpng.c:675-677)
+        if (threadIdx.x == 0) w32(0, r.size);
+        const uint64_t row = (uint64_t)t.w * 3;
+        for (uint32_t y = 0; y < t.h; y++) block_copy(dst + 4 + y * row, src + y * bpr, row);
+        return;
+    }
+    if (r.kind == 3) {  // raw gray (libxpng.c:616-618)
+        if (threadIdx.x == 0) w32(0, (t.n + 4) + (5u << 27));
+        for (uint32_t i = threadIdx.x; i < t.n; i += 256) { const uint32_t y = i / t.w, x = i - y * t.w; dst[4 + i] = src[(uint64_t)y * bpr + (uint64_t)x * 3]; }
+        return;
+    }
+    const uint32_t bsz = 4 + 4 * ((r.bbits + 31) >> 5);
+    if (threadIdx.x == 0) {
+        if (r.kind == 2) w32(0, r.size + (2u << 28) + (r.m << 24));
+        else w32(0, r.size + (1u << 28) + (((uint32_t)pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3u) << 24));
+        w32(4, bsz);
+    }
+    block_copy(dst + 8, sc + m2_off_bits(t.n), bsz - 4);
+    uint32_t o = 4 + bsz;
+    if (r.kind == 2) {
+        const uint32_t s = 17 + r.m;
+        m2_write_block(dst + o, b[s], reinterpret_cast<const uint32_t *>(sc + m2_off_blk(t.n, s)));
+    } else {
+        for (uint32_t s = 0; s < M2_STREAMS; s++) {
+            m2_write_block(dst + o, b[s], reinterpret_cast<const uint32_t *>(sc + m2_off_blk(t.n, s)));
+            o += m2_blk_bytes(b[s]);
+        }
+    }
+}
+
+}  // namespace xpng

@@ -47,22 +47,13 @@ struct BitW {
     }
 };
 
-// Encode one block.  `in` = symbol bytes (global), n = count, nominalN = 9 or 256, pb = 12 or 15,
-// out = 4-byte aligned global buffer with the capacity of common.hpp.  Returns the block size in bytes
-// (uniform across the wave).  Must be called by all 64 lanes of a single-wave workgroup.
-// LDS: hist[256], cum[257], tab[256].
-__device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, uint32_t n, uint32_t nominalN, int pb,
-                                              uint8_t *__restrict__ out8, uint32_t *hist, uint32_t *cum, EncSym *tab,
-                                              uint64_t *stamp = nullptr) {
+// ---- phases shared by the v2 (mode 1) and v1 (mode 2) block encoders; all are wave-cooperative (64 lanes, one wave
+// per workgroup) and communicate through LDS arrays owned by the kernel.
+
+// symbol histogram of in[0..n) into hist[256]
+__device__ inline void rans_histogram(const uint8_t *__restrict__ in, uint32_t n, uint32_t *hist) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t *out = reinterpret_cast<uint32_t *>(out8);
-    if (n == 0) {  // libxpng.c:313
-        if (lane == 0) out[0] = 4;
-        return 4;
-    }
-#define XPNG_STAMP(k) do { if (stamp && lane == 0) stamp[k] = __builtin_readcyclecounter(); } while (0)
-    XPNG_STAMP(0);
-    // ---- histogram (the reference counts F[] while routing; same numbers).  16 symbols per lane per load; four
+    // (the reference counts F[] while routing; same numbers).  16 symbols per lane per load; four
     // sub-histograms (lane & 3) cut the same-address LDS atomic serialisation of skewed streams.
     __shared__ uint32_t hsub[4][256];
     for (uint32_t i = lane; i < 1024; i += 64) (&hsub[0][0])[i] = 0;
@@ -90,19 +81,22 @@ __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, ui
     __syncthreads();
     for (uint32_t i = lane; i < 256; i += 64) hist[i] = hsub[0][i] + hsub[1][i] + hsub[2][i] + hsub[3][i];
     __syncthreads();
-    XPNG_STAMP(1);
-    // ---- alphabet: N = 1 + highest used symbol, distinct count (libxpng.c:314-317)
-    uint32_t top = 0, distinct = 0;
+}
+
+// N = 1 + highest used symbol (returned as top), number of distinct symbols (libxpng.c:314-317)
+__device__ inline void rans_alphabet(const uint32_t *hist, uint32_t nominalN, uint32_t &top, uint32_t &distinct) {
+    const uint32_t lane = threadIdx.x & 63;
+    top = 0; distinct = 0;
     for (uint32_t i = lane; i < nominalN; i += 64) {
         if (hist[i]) { top = i; distinct++; }
     }
     top = ~wave_min_u32(~top);  // max
     distinct = wave_sum_u32(distinct);
-    const uint32_t N = top + 1, rawBits = (uint32_t)bit_width(top);
-    if (distinct == 1) {  // libxpng.c:318
-        if (lane == 0) { out[0] = 8u | (1u << 24); out[1] = n | ((uint32_t)in[0] << 24); }
-        return 8;
-    }
+}
+
+// scaled cumulative counts + "steal" repair + encoder entries; on return hist[i] = normalised F[i] for i < N
+__device__ inline void rans_tables(uint32_t *hist, uint32_t *cum, EncSym *tab, uint32_t N, uint32_t n, int pb) {
+    const uint32_t lane = threadIdx.x & 63;
     // ---- cumulative counts, scaled to 2^pb (libxpng.c:317,320).  N <= 256: serial prefix by lane 0 is
     // 256 LDS steps; do it as 4-per-lane partial sums + wave scan instead.
     {
@@ -164,6 +158,33 @@ __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, ui
     for (uint32_t i = lane; i < N; i += 64) hist[i] = cum[i + 1] - cum[i];  // hist := normalised F
     __syncthreads();
 
+}
+
+// Encode one block.  `in` = symbol bytes (global), n = count, nominalN = 9 or 256, pb = 12 or 15,
+// out = 4-byte aligned global buffer with the capacity of common.hpp.  Returns the block size in bytes
+// (uniform across the wave).  Must be called by all 64 lanes of a single-wave workgroup.
+// LDS: hist[256], cum[257], tab[256].
+__device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, uint32_t n, uint32_t nominalN, int pb,
+                                              uint8_t *__restrict__ out8, uint32_t *hist, uint32_t *cum, EncSym *tab,
+                                              uint64_t *stamp = nullptr) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *out = reinterpret_cast<uint32_t *>(out8);
+    if (n == 0) {  // libxpng.c:313
+        if (lane == 0) out[0] = 4;
+        return 4;
+    }
+#define XPNG_STAMP(k) do { if (stamp && lane == 0) stamp[k] = __builtin_readcyclecounter(); } while (0)
+    XPNG_STAMP(0);
+    rans_histogram(in, n, hist);
+    XPNG_STAMP(1);
+    uint32_t top, distinct;
+    rans_alphabet(hist, nominalN, top, distinct);
+    const uint32_t N = top + 1, rawBits = (uint32_t)bit_width(top);
+    if (distinct == 1) {  // libxpng.c:318
+        if (lane == 0) { out[0] = 8u | (1u << 24); out[1] = n | ((uint32_t)in[0] << 24); }
+        return 8;
+    }
+    rans_tables(hist, cum, tab, N, n, pb);
     XPNG_STAMP(2);
     // ---- the recurrence (libxpng.c:362-392).  Even lanes run state0 (even symbols), odd lanes state1 (odd
     // symbols); lanes 2..63 replicate lanes 0/1 so the loop has no per-lane validity masks (they never write).

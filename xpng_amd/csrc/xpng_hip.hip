@@ -14,6 +14,8 @@
 #include "common.hpp"
 #include "m1_decode.hpp"
 #include "m1_encode.hpp"
+#include "m2_decode.hpp"
+#include "m2_encode.hpp"
 #include "rans2.hpp"
 #include "tile_container.hpp"
 
@@ -85,6 +87,14 @@ struct xpnghip_ctx {
     uint8_t **d_out_ptrs = nullptr;       // B blob (encode) / raster (decode) pointers
     std::vector<const void *> h_in_ptrs;  // what d_in_ptrs / d_out_ptrs currently hold (skip the upload when unchanged)
     std::vector<void *> h_out_ptrs;
+    // mode 2 (RGB slow level): allocated on first use
+    uint8_t *d_scratch2 = nullptr;
+    uint64_t *d_sbase2 = nullptr;
+    uint32_t *d_flags2 = nullptr, *d_stream_n2 = nullptr;
+    M2Blk *d_blk2 = nullptr;
+    M2Tile *d_mt2 = nullptr;
+    M2DecTile *d_info2 = nullptr;
+    uint16_t *d_tabs2 = nullptr;
     int stamps = 0;  // XPNG_STAMPS=1: chain kernels record s_memtime phase stamps (debug_fetch 40/41)
     uint64_t *h_total = nullptr;  // pinned, B entries
     hipStream_t stream = nullptr;
@@ -98,7 +108,8 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
-                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs};
+                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs,
+                    c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     decode_ws_free(c->dec);
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -256,17 +267,61 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     return 0;
 }
 
+static int ensure_m2(xpnghip_ctx *c) {
+    if (c->d_scratch2) return 0;
+    const uint64_t N = c->tiles.size(), VN = N * c->B;
+    std::vector<uint64_t> sb(VN);
+    uint64_t o = 0;
+    for (uint64_t v = 0; v < VN; v++) { sb[v] = o; o += m2_tile_scratch(c->tiles[v % N].n); }
+    if (hipMalloc((void **)&c->d_scratch2, o + 8192) != hipSuccess || hipMalloc((void **)&c->d_sbase2, VN * 8) != hipSuccess ||
+        hipMalloc((void **)&c->d_flags2, VN * 4) != hipSuccess || hipMalloc((void **)&c->d_stream_n2, VN * M2_SLOTS * 4) != hipSuccess ||
+        hipMalloc((void **)&c->d_blk2, VN * M2_SLOTS * sizeof(M2Blk)) != hipSuccess || hipMalloc((void **)&c->d_mt2, VN * sizeof(M2Tile)) != hipSuccess ||
+        hipMalloc((void **)&c->d_info2, VN * sizeof(M2DecTile)) != hipSuccess || hipMalloc((void **)&c->d_tabs2, VN * M2_SLOTS * 512) != hipSuccess)
+        return fail("hipMalloc failed (mode-2 workspace)");
+    c->ws_bytes += o + 8192;
+    HIPCHK(hipMemcpy(c->d_sbase2, sb.data(), VN * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// mode 2: RGB only (libxpng.c:755 sends RGBA to mode 1 before the tile stage)
+static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+    if (ensure_m2(c)) return 1;
+    const uint32_t cnt = t1 - t0, total = nimg * cnt;
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
+    const uint64_t bpr = c->W * 3, VN = (uint64_t)c->B * sel.N;
+    uint32_t max_n = 0;
+    for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
+    HIPCHK(hipMemsetAsync(c->d_flags2, 0, VN * 4, s));
+    HIPCHK(hipMemsetAsync(c->d_stream_n2, 0, VN * M2_SLOTS * 4, s));
+    HIPCHK(hipMemsetAsync(c->d_blk2, 0, VN * M2_SLOTS * sizeof(M2Blk), s));
+    k_m2_classify<<<total * 16, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, 16, c->d_flags2);
+    if (launch_transform<3>(c, nimg, t0, t1, s)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes
+    k_m2_streams<<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
+    const uint32_t gbpt = (max_n + 255) / 256;
+    k_m2_gray_syms<<<total * gbpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, gbpt, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
+    k_rans1_encode<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2);
+    k_m2_select<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, c->d_flags2, c->d_blk2, c->d_mt2, c->d_tile_sz);
+    k_m2_bits<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2);
+    k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
+    k_m2_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_sums, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2, c->d_off, c->d_out_ptrs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
 extern "C" int xpnghip_encode_device_batch(xpnghip_ctx *c, int mode, const void *const *d_rasters, uint32_t nimg, uint64_t t0,
                                            uint64_t t1, void *const *d_blobs, uint64_t *blobs_len, void *stream) {
     if (check_range(c, t0, t1)) return 1;
-    if (mode != 1) return fail("only mode 1 is implemented on the device in this build");
+    if (mode != 1 && mode != 2) return fail("tile mode must be 1 or 2");
+    if (mode == 2 && c->pxsz != 3) return fail("mode 2 codes RGB only (the driver sends RGBA to mode 1, libxpng.c:755)");
     if (c->pxsz == 4)
         for (uint64_t i = t0; i < t1; i++)
             if (c->tiles[i].w < 4 || c->tiles[i].h < 4) return fail("RGBA tile narrower than 4 px: undefined in the reference; store level 7");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (set_ptrs(c, d_rasters, d_blobs, nimg, s)) return 1;
-    const int rc = c->pxsz == 4 ? launch_encode_m1<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_encode_m1<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
+    const int rc = mode == 2 ? launch_encode_m2(c, nimg, (uint32_t)t0, (uint32_t)t1, s)
+                   : c->pxsz == 4 ? launch_encode_m1<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_encode_m1<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
     if (rc) return rc;
     if (blobs_len) {
         HIPCHK(hipStreamSynchronize(s));
@@ -284,10 +339,16 @@ extern "C" uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *c, uint32_t img) 
 extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void *const *d_blobs, uint32_t nimg,
                                            const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *const *d_rasters, void *stream) {
     if (check_range(c, t0, t1)) return 1;
-    if (mode != 1) return fail("only mode 1 is implemented on the device in this build");
+    if (mode != 1 && mode != 2) return fail("tile mode must be 1 or 2");
+    if (mode == 2 && c->pxsz != 3) return fail("mode 2 codes RGB only");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (set_ptrs(c, d_blobs, d_rasters, nimg, s)) return 1;
+    if (mode == 2) {
+        if (ensure_m2(c)) return 1;
+        return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, c->d_in_ptrs, tile_off, (uint32_t)t0,
+                                (uint32_t)t1, c->d_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
+    }
     return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, c->pxsz, c->d_in_ptrs, tile_off,
                             (uint32_t)t0, (uint32_t)t1, c->d_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr);
 }
