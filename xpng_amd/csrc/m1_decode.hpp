@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
                                                      const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first,
                                                      uint32_t c_count, int only_over, uint8_t *__restrict__ ctxsym,
                                                      uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg) {
-    __shared__ uint8_t slot2sym[1 << MAXPB];
+    __shared__ uint8_t coarse[1 << (MAXPB - 3)];  // symbol owning slot (i << 3): start of a short forward scan (8x less LDS than a
+                                                    // full slot table, which is what bounds the number of resident chains per CU)
     __shared__ uint32_t fc[256];
     __shared__ uint32_t Fs[260];
     __shared__ uint32_t wring[512];
@@ -201,16 +202,17 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
         hot1 = wmax(m2);
     }
     __syncthreads();
-    {   // slot -> symbol: every lane fills slots by binary search over cum (N <= 256 -> 8 probes)
-        const uint32_t scale = 1u << pb;
-        for (uint32_t s = lane; s < scale; s += 64) {
+    {   // coarse slot -> symbol: binary search over cum for every 8th slot (N <= 256 -> 8 probes)
+        const uint32_t groups = 1u << (pb - 3);
+        for (uint32_t g = lane; g < groups; g += 64) {
+            const uint32_t s = g << 3;
             uint32_t lo = 0, hi = N - 1;  // largest index with cum <= s
             while (lo < hi) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
                 if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
             }
             while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
-            slot2sym[s] = (uint8_t)lo;
+            coarse[g] = (uint8_t)lo;
         }
     }
     __syncthreads();
@@ -249,8 +251,9 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
         if (__ballot(!(hit0 || hit1)) == 0) {
             F = hit0 ? F0 : F1; off = hit0 ? d0 : d1; sym = hit0 ? sym0 : sym1;
         } else {
-            sym = slot2sym[slot];
-            const uint32_t e = fc[sym];
+            sym = coarse[slot >> 3];
+            uint32_t e = fc[sym];
+            while (slot - (e >> 16) >= (e & 0xFFFF) && sym + 1 < N) e = fc[++sym];  // walk to the symbol whose [cum, cum+F) holds the slot
             F = e & 0xFFFF; off = slot - (e >> 16);
         }
         s = (uint64_t)F * (s >> pb) + off;
@@ -362,16 +365,15 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ 
 // (lanes 0..8), total = number of symbols to produce.  Single-wave workgroup.
 __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in, uint32_t total, uint8_t *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63;
-    // queue supply: every queue is staged through its own 2 KB LDS ring in 1 KB units (coalesced copies by the whole
+    // queue supply: every queue is staged through its own 1 KB LDS ring in 512-byte units (coalesced copies by half a
     // wave, triggered at 8-step block boundaries when a queue's read position nears the end of what is staged).
-    __shared__ __align__(16) uint8_t qring[9][2048];
+    __shared__ __align__(16) uint8_t qring[9][1024];
     const uint32_t qs = lane < 9 ? qs_in : 0;
     const uint32_t qsa = qs & ~15u;  // 16-byte aligned start of this lane's queue inside the tile's symbol area
     for (uint32_t c = 0; c < 9; c++) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, (int)c);
         const uint4 *src = reinterpret_cast<const uint4 *>(base + a) + lane;
-        reinterpret_cast<uint4 *>(qring[c])[lane] = src[0];
-        reinterpret_cast<uint4 *>(qring[c])[64 + lane] = src[64];
+        reinterpret_cast<uint4 *>(qring[c])[lane] = src[0];  // 64 lanes x 16 B = both 512-byte units
     }
     __syncthreads();
     uint32_t filled = 2;                      // units staged for this lane's queue
@@ -382,7 +384,7 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
     uint32_t rdpos = (p0 & ~7u) + 8;          // next ring position to load into the register window
     uint32_t cur = 0;
     auto restage = [&]() {  // uniform entry; copies one more unit for every queue that is within 32 bytes of its staged end
-        uint64_t m = __ballot(lane < 9 && rdpos + 32 >= filled * 1024u);
+        uint64_t m = __ballot(lane < 9 && rdpos + 32 >= filled * 512u);
         if (m == 0) return;
         __syncthreads();
         while (m) {
@@ -390,8 +392,10 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
             m &= m - 1;
             const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, c);
             const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)filled, c);
-            const uint4 v = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * 64];
-            reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * 64 + lane] = v;
+            if (lane < 32) {
+                const uint4 v = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * 32];
+                reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * 32 + lane] = v;
+            }
             if ((int)lane == c) filled++;
         }
         __syncthreads();
@@ -402,7 +406,7 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
         win >>= mine ? 8 : 0;
         have -= mine ? 1u : 0u;
         if (have == 0) {  // divergent, once per 8 pops of a queue: next 8 symbols from the LDS ring
-            win = *reinterpret_cast<const uint64_t *>(&qring[ql][rdpos & 2047u]);
+            win = *reinterpret_cast<const uint64_t *>(&qring[ql][rdpos & 1023u]);
             rdpos += 8;
             have = 8;
         }

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
                                                      uint32_t s_first, uint32_t s_count, const M2Blk *__restrict__ blk,
                                                      const uint16_t *__restrict__ tabs, uint8_t *__restrict__ scratch2,
                                                      const uint64_t *__restrict__ sbase2) {
-    __shared__ uint8_t slot2sym[1 << MAXPB];
+    __shared__ uint8_t coarse[1 << (MAXPB - 3)];  // symbol owning slot (i << 3): start of a short forward scan (8x less LDS than a
+                                                    // full slot table, which is what bounds the number of resident chains per CU)
     __shared__ uint32_t fc[256];
     __shared__ uint32_t wring[512];
     __shared__ uint8_t oring[512];
@@ -153,16 +154,17 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
         hot1 = wmax(m2);
     }
     __syncthreads();
-    {
-        const uint32_t scale = 1u << pb;
-        for (uint32_t s = lane; s < scale; s += 64) {
-            uint32_t lo = 0, hi = Nnom - 1;
+    {   // coarse slot -> symbol: binary search over cum for every 8th slot (Nnom <= 256 -> 8 probes)
+        const uint32_t groups = 1u << (pb - 3);
+        for (uint32_t g = lane; g < groups; g += 64) {
+            const uint32_t s = g << 3;
+            uint32_t lo = 0, hi = Nnom - 1;  // largest index with cum <= s
             while (lo < hi) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
                 if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
             }
-            while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;
-            slot2sym[s] = (uint8_t)lo;
+            while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
+            coarse[g] = (uint8_t)lo;
         }
     }
     __syncthreads();
@@ -196,7 +198,12 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
         const bool hit0 = d0 < F0, hit1 = d1 < F1;
         uint32_t F, offv;
         if (__ballot(!(hit0 || hit1)) == 0) { F = hit0 ? F0 : F1; offv = hit0 ? d0 : d1; sym = hit0 ? sym0 : sym1; }
-        else { sym = slot2sym[slt]; const uint32_t e = fc[sym]; F = e & 0xFFFF; offv = slt - (e >> 16); }
+        else {
+            sym = coarse[slt >> 3];
+            uint32_t e = fc[sym];
+            while (slt - (e >> 16) >= (e & 0xFFFF) && sym + 1 < Nnom) e = fc[++sym];  // walk to the symbol whose [cum, cum+F) holds the slot
+            F = e & 0xFFFF; offv = slt - (e >> 16);
+        }
         return (uint64_t)F * (s >> pb) + offv;
     };
     const uint32_t pairs = sgpr(n >> 1);

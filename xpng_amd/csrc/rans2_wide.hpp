@@ -1,0 +1,209 @@
+// rans2_wide.hpp -- throughput form of the mode-1 entropy ENCODE stage: every lane runs a chain.
+//
+// k_rans2_encode (tile_container.hpp) gives one wavefront to one (tile, stream) pair, i.e. two live lanes out of 64.  That
+// is the right shape for a single image (the stage is latency-bound by the longest chain), but a batch needs wave slots
+// in proportion to tiles x streams.  Here the same block bytes are produced by three launches:
+//
+//   k_rans2_prep    wave per (tile, stream): histogram -> alphabet -> tables (rans_* helpers of rans2.hpp); empty and
+//                   one-symbol blocks are finished on the spot; otherwise the encoder table and the normalised
+//                   frequencies go to global memory
+//   k_rans2_chain   wave per WIDE_TILES tiles: lane = one rANS state of one stream (2 x streams lanes per tile).  Tables in
+//                   LDS; each lane streams its own symbols through a register window straight from global memory; the
+//                   spill position inside a pair comes from a DPP lane swap (state0's word first); words go straight to
+//                   the block's word area.  The wave runs for its longest chain.
+//   k_rans2_finish  wave per (tile, stream): states, header, frequency table, type-2 (raw) fallback
+#pragma once
+#include "common.hpp"
+#include "rans2.hpp"
+
+namespace xpng {
+
+constexpr uint32_t WIDE_TILES = 3;
+constexpr uint32_t WTAB_TILE_BYTES = 4096 + 9 * 256;  // alpha table (256 x 16 B) + nine context tables (16 x 16 B)
+struct WPrep {
+    uint32_t kind;  // 0 = block already final (size in `cnt`), 1 = needs chain + finish
+    uint32_t N, distinct, cnt;  // cnt: words emitted by the chain (kind 1)
+    uint64_t st[2];             // final states
+};
+__device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 + c * 256 : 0; }
+
+__global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
+                                                   const uint8_t *__restrict__ planes, uint64_t plane_stride,
+                                                   uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
+                                                   uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
+                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t cum[260];
+    __shared__ EncSym tab[256];
+    const uint32_t tile = vtile(sel, blockIdx.x / spt), c = blockIdx.x % spt, lane = threadIdx.x & 63;
+    const TileDesc t = tiles[tile];
+    uint8_t *sc = scratch + t.sbase;
+    const uint8_t *in;
+    uint32_t n, nominalN;
+    int pb;
+    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
+    else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + off_blk(t.n, (int)c));
+    WPrep *p = prep + (uint64_t)tile * 10 + c;
+    if (n == 0) {  // libxpng.c:313
+        if (lane == 0) { out[0] = 4; blk_sz[(uint64_t)tile * 10 + c] = 4; *p = WPrep{0, 0, 0, 4, {0, 0}}; }
+        return;
+    }
+    rans_histogram(in, n, hist);
+    uint32_t top, distinct;
+    rans_alphabet(hist, nominalN, top, distinct);
+    if (distinct == 1) {  // libxpng.c:318
+        if (lane == 0) {
+            out[0] = 8u | (1u << 24); out[1] = n | ((uint32_t)in[0] << 24);
+            blk_sz[(uint64_t)tile * 10 + c] = 8; *p = WPrep{0, 1, 1, 8, {0, 0}};
+        }
+        return;
+    }
+    const uint32_t N = top + 1;
+    rans_tables(hist, cum, tab, N, n, pb);
+    EncSym *gt = reinterpret_cast<EncSym *>(wtab + (uint64_t)tile * WTAB_TILE_BYTES + wtab_off(c));
+    uint16_t *gF = wF + ((uint64_t)tile * 10 + c) * 256;
+    for (uint32_t i = lane; i < N; i += 64) { gt[i] = tab[i]; gF[i] = (uint16_t)hist[i]; }
+    if (lane == 0) *p = WPrep{1, N, distinct, 0, {0, 0}};
+}
+
+__global__ __launch_bounds__(64) void k_rans2_chain(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total, uint32_t spt,
+                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
+                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
+                                                    WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
+    __shared__ __align__(16) uint8_t ltab[WIDE_TILES * WTAB_TILE_BYTES];
+    const uint32_t lane = threadIdx.x & 63, lpt = 2 * spt;  // lanes per tile
+    const uint32_t tsel = lane / lpt, r = lane - tsel * lpt, c = r >> 1, par = r & 1;
+    const uint32_t j = blockIdx.x * WIDE_TILES + tsel;
+    bool live = tsel < WIDE_TILES && j < total;
+    const uint32_t tile = live ? vtile(sel, j) : vtile(sel, 0);
+    // tables of the wave's tiles -> LDS (whole 6.4 KB records; unused entries are never read)
+    for (uint32_t ts = 0; ts < WIDE_TILES; ts++) {
+        const uint32_t jj = blockIdx.x * WIDE_TILES + ts;
+        if (jj >= total) break;
+        const uint4 *src = reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES);
+        uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * WTAB_TILE_BYTES);
+        for (uint32_t i = lane; i < WTAB_TILE_BYTES / 16; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const TileDesc t = tiles[tile];
+    uint8_t *sc = scratch + t.sbase;
+    const uint8_t *in;
+    uint32_t n;
+    int pb;
+    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = live ? ctx_n[(uint64_t)tile * 9 + c] : 0; pb = 12; }
+    else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; pb = 15; }
+    WPrep *p = prep + (uint64_t)tile * 10 + c;
+    live = live && p->kind == 1;
+    const uint32_t mysteps = live ? ((n + 1 - par) >> 1) : 0;  // state0 codes ceil(n/2) symbols, state1 floor(n/2)
+    uint32_t maxsteps = mysteps;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(maxsteps, o); maxsteps = v > maxsteps ? v : maxsteps; }
+    maxsteps = sgpr(maxsteps);
+    const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (tsel < WIDE_TILES ? tsel : 0) * WTAB_TILE_BYTES + wtab_off(c));
+    uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t.n, (int)c)) + 3;
+    // per-lane symbol window: 4 of this lane's (stride-2) symbols per 8-byte chunk, one chunk prefetched
+    const uintptr_t A = (uintptr_t)(in + par);
+    const uint64_t *chunk = reinterpret_cast<const uint64_t *>(A & ~(uintptr_t)7);
+    const uint32_t off = (uint32_t)(A & 7), bp8 = (off & 1) * 8;
+    uint64_t win = live ? (chunk[0] >> bp8) >> (16 * (off >> 1)) : 0;
+    uint32_t have = 4 - (off >> 1);
+    uint64_t nxt = live ? chunk[1] : 0;
+    chunk += 2;
+    uint32_t fetched = 0;  // symbols handed out so far (a lane stops loading once its own chain is covered)
+    auto next_sym = [&]() -> uint32_t {
+        const uint32_t sy = (uint32_t)win & 0xFFu;
+        win >>= 16;
+        fetched++;
+        if (--have == 0) { win = nxt >> bp8; have = 4; if (fetched < mysteps) nxt = *chunk; chunk++; }
+        return sy;
+    };
+    const uint32_t cmpl_base = 1u << pb;
+    const int thr_shift = 31 - pb;
+    uint64_t s = RANS_L;
+    uint32_t cnt = 0;
+    EncSym e = tab[next_sym()];
+    for (uint32_t k = 0; k < maxsteps; k++) {
+        const EncSym en = tab[next_sym()];  // table entry of the NEXT step: its LDS latency hides under this step's arithmetic
+        const bool act = k < mysteps;
+        const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
+        const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
+        const uint32_t other = swap_pair(emit);
+        if (emit) { w[cnt + (par ? other : 0u)] = (uint32_t)s; s >>= 32; }  // state0's word first (libxpng.c:370-373)
+        cnt += emit + other;
+        if (act) {
+            const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
+            const uint64_t q = __umul64hi(s, rcp) >> rsh;
+            s += e.bias + q * (uint64_t)(cmpl_base - freq);
+        }
+        e = en;
+    }
+    if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
+}
+
+__global__ __launch_bounds__(64) void k_rans2_finish(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
+                                                     const uint8_t *__restrict__ planes, uint64_t plane_stride,
+                                                     uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
+                                                     uint32_t *__restrict__ blk_sz, const WPrep *__restrict__ prep,
+                                                     const uint16_t *__restrict__ wF) {
+    const uint32_t tile = vtile(sel, blockIdx.x / spt), c = blockIdx.x % spt, lane = threadIdx.x & 63;
+    const WPrep p = prep[(uint64_t)tile * 10 + c];
+    if (p.kind != 1) return;
+    const TileDesc t = tiles[tile];
+    uint8_t *sc = scratch + t.sbase;
+    const uint8_t *in;
+    uint32_t n;
+    int pb;
+    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; pb = 12; }
+    else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; pb = 15; }
+    uint8_t *out8 = sc + off_blk(t.n, (int)c);
+    uint32_t *out = reinterpret_cast<uint32_t *>(out8);
+    const uint16_t *F16 = wF + ((uint64_t)tile * 10 + c) * 256;
+    const uint32_t N = p.N, distinct = p.distinct, rawBits = (uint32_t)bit_width(N - 1);
+    uint32_t *w = out + 3 + p.cnt;
+    if (lane < 2) { w[2 * lane] = (uint32_t)p.st[lane]; w[2 * lane + 1] = (uint32_t)(p.st[lane] >> 32); }  // libxpng.c:394
+    w += 4;
+    // ---- header + frequency table (libxpng.c:396-415)
+    const uint32_t sparseBits = N + distinct * (uint32_t)pb;
+    const bool sparse = sparseBits < N * (uint32_t)pb;
+    uint32_t csz = 0;
+    if (lane == 0) {
+        out[1] = n | ((N - 2) << 24);
+        out[2] = (uint32_t)(w - (out + 2)) | ((uint32_t)pb << 24);
+        BitW tb{0, 0, w};
+        for (uint32_t k = 0; k < N; k++) {
+            const uint32_t F = F16[k];
+            if (!sparse) tb.put((uint32_t)pb, F);
+            else if (F) tb.put((uint32_t)pb + 1, F + (1u << pb));
+            else tb.put(1, 0);
+        }
+        tb.finish();
+        csz = (uint32_t)((uint8_t *)tb.p - out8);
+        out[0] = csz | ((3u + (sparse ? 1u : 0u)) << 24);
+    }
+    csz = __shfl(csz, 0);
+    // ---- raw fallback, type 2 (libxpng.c:417-424)
+    const uint64_t rawTotalBits = (uint64_t)rawBits * n;
+    const uint32_t rawWords = (uint32_t)((rawTotalBits + 31) >> 5);
+    if (csz >= 8 + 4 * rawWords) {
+        __syncthreads();
+        for (uint32_t wi = lane; wi < rawWords; wi += 64) {
+            const uint64_t b0 = (uint64_t)wi * 32;
+            uint32_t jx = (uint32_t)(b0 / rawBits);
+            uint32_t word = 0;
+            for (; jx < n; jx++) {
+                const int64_t rel = (int64_t)((uint64_t)jx * rawBits) - (int64_t)b0;
+                if (rel >= 32) break;
+                const int sh = 32 - (int)rel - (int)rawBits;
+                const uint32_t v = in[jx];
+                word |= sh >= 0 ? (sh < 32 ? v << sh : 0u) : v >> (-sh);
+            }
+            out[2 + wi] = word;
+        }
+        csz = 8 + 4 * rawWords;
+        if (lane == 0) { out[0] = csz | (2u << 24); out[1] = n | (rawBits << 24); }
+    }
+    if (lane == 0) blk_sz[(uint64_t)tile * 10 + c] = csz;
+}
+
+}  // namespace xpng

@@ -17,6 +17,7 @@
 #include "m2_decode.hpp"
 #include "m2_encode.hpp"
 #include "rans2.hpp"
+#include "rans2_wide.hpp"
 #include "tile_container.hpp"
 
 using namespace xpng;
@@ -87,6 +88,9 @@ struct xpnghip_ctx {
     uint8_t **d_out_ptrs = nullptr;       // B blob (encode) / raster (decode) pointers
     std::vector<const void *> h_in_ptrs;  // what d_in_ptrs / d_out_ptrs currently hold (skip the upload when unchanged)
     std::vector<void *> h_out_ptrs;
+    WPrep *d_wprep = nullptr;   // wide entropy stage: per (tile, stream) record, encoder tables, normalised frequencies
+    uint8_t *d_wtab = nullptr;
+    uint16_t *d_wF = nullptr;
     // mode 2 (RGB slow level): allocated on first use
     uint8_t *d_scratch2 = nullptr;
     uint64_t *d_sbase2 = nullptr;
@@ -109,7 +113,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs,
-                    c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
+                    c->d_wprep, c->d_wtab, c->d_wF, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     decode_ws_free(c->dec);
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -156,6 +160,9 @@ extern "C" int xpnghip_ctx_create_batch(xpnghip_ctx **out, int device, uint64_t 
     ALLOC(c->d_off, (VN + batch) * 8);
     ALLOC(c->d_totals, (uint64_t)batch * 8);
     ALLOC(c->d_dbg, VN * 10 * 8 * 8 * 2);
+    ALLOC(c->d_wprep, VN * 10 * sizeof(WPrep));
+    ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096);
+    ALLOC(c->d_wF, VN * 10 * 512);
     ALLOC(c->d_in_ptrs, (uint64_t)batch * 8);
     ALLOC(c->d_out_ptrs, (uint64_t)batch * 8);
 #undef ALLOC
@@ -258,7 +265,13 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * PXSZ;
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
     k_m1_streams<PXSZ><<<total, ST_THREADS, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
+    if (getenv("XPNG_NARROW_RANS")) {  // one wave per (tile, stream): lowest single-image latency path kept for A/B runs
+        k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
+    } else {                           // every lane a chain: prep -> chain -> finish
+        k_rans2_prep<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
+        k_rans2_chain<<<(total + WIDE_TILES - 1) / WIDE_TILES, 64, 0, s>>>(c->d_tiles, sel, total, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
+    }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
     k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
     k_tile_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
