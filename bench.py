@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--roofline-reps", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")
+    ap.add_argument("--batch", type=int, default=64,
                     help="images per launch per rank: a step encodes+decodes `batch` rasters of the workload in one batched launch "
                          "sequence (the entropy stage is a serial chain per tile stream, so one image alone cannot fill 256 CUs)")
     args = ap.parse_args()
@@ -112,7 +113,7 @@ def main():
 
     import xpng_amd
     from xpng_amd.api import walk_tile_offsets
-    from xpng_amd.shard import band_rows, gather_blobs, weighted_tile_ranges
+    from xpng_amd.shard import band_rows, gather_blobs_batch, tile_table, weighted_tile_ranges
     from xpng_amd.synth import seven_header, synth_raster_torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,10 +123,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the xPNG tile codec has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % ndev  # (a rehearsal may run several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     alpha = not args.rgb
     ch = 4 if alpha else 3
@@ -137,11 +143,16 @@ def main():
         W, H = args.share * a, args.share * b
         scaling = "weak"
     B = max(1, args.batch)
-    ctx = xpng_amd.Context(W, H, ch, device=local_rank, batch=B)  # one context, B images per launch
-    tiles = ctx.tiles()
+    tiles = tile_table(W, H)
     t0, t1 = weighted_tile_ranges(tiles, world)[rank]
+    # one context, B images per launch, workspace only for this rank's tile range
+    ctx = xpng_amd.Context(W, H, ch, device=local_rank, batch=B, tile_range=(t0, t1))
+    assert ctx.tiles() == tiles
     y0, y1 = band_rows(tiles, t0, t1)
-    band = synth_raster_torch(args.kind, W, y1 - y0, alpha, y0=y0, device=f"cuda:{local_rank}")
+    # the rank materialises only the raster band its tiles touch (+ one spare row: the staged 16-byte loads of the last
+    # row may run a few bytes past it when the band is not the tail of the image)
+    band_store = synth_raster_torch(args.kind, W, min(H, y1 + 1) - y0, alpha, y0=y0, device=f"cuda:{local_rank}")
+    band = band_store[: y1 - y0]
     bpr = W * ch
     d_raster_virtual = band.data_ptr() - y0 * bpr  # kernels address rows absolutely; only [y0, y1) is ever touched
     d_blobs_all = [torch.empty(ctx.blob_bound(t0, t1) + 64, dtype=torch.uint8, device=band.device) for _ in range(B)]
@@ -167,7 +178,21 @@ def main():
     for (tx, ty, tw, th) in tiles[t0:t1]:
         ok = ok and torch.equal(d_back[ty - y0:ty - y0 + th, tx:tx + tw], band[ty - y0:ty - y0 + th, tx:tx + tw])
     verified = {"roundtrip": bool(ok)}
-    gathered, lens = gather_blobs(d_blobs, n) if world > 1 else (blobs_local, [n])
+    use_host = world > 1 and args.backend != "nccl"
+
+    def exchange():  # the one exchange of the path: every rank's B blobs -> rank 0 (RCCL send/recv; no collective on the data path)
+        if not use_host:
+            return gather_blobs_batch(d_blobs_all, [n] * B)
+        outs, table = gather_blobs_batch([t[:n].cpu() for t in d_blobs_all], [n] * B)
+        return outs, table
+
+    if world > 1:
+        for bi in range(1, B):
+            d_blobs_all[bi][:n].copy_(d_blobs_all[0][:n])  # (only image 0 has been encoded so far)
+        outs, table = exchange()
+        gathered, lens = (outs[0] if rank == 0 else None), [row[0] for row in table]
+    else:
+        gathered, lens = blobs_local, [n]
     if rank == 0:
         man_path = os.path.join(ROOT, "tests", "golden", "manifest.json")
         key = f"synth_{args.kind}_{W}x{H}_{'rgba' if alpha else 'rgb'}"
@@ -175,6 +200,7 @@ def main():
             man = json.load(open(man_path))
             if key in man and "L1" in man[key]:
                 md = hashlib.md5(seven_header(W, H, alpha, level=1) + gathered.cpu().numpy().tobytes()).hexdigest()
+                verified["reference_size"] = 8 + int(sum(lens)) == man[key]["L1"]["size"]
                 verified["reference_md5"] = md == man[key]["L1"]["md5"]
                 ok = ok and verified["reference_md5"]
     if not ok:
@@ -184,8 +210,7 @@ def main():
         # one launch sequence covers all B images (virtual tile = image * N + tile)
         ctx.encode_device_batch(1, rast_ptrs, blob_ptrs, t0, t1, stream=stream, sync=False)
         if world > 1:
-            for b in range(B):
-                gather_blobs(d_blobs_all[b], n)  # tile bytes are deterministic: n is the length verified above
+            exchange()  # tile bytes are deterministic: n is the length verified above
         ctx.decode_device_batch(1, blob_ptrs, [off] * B, back_ptrs, t0, t1, stream=stream)
 
     def barrier():
@@ -240,7 +265,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' {'RGBA8' if alpha else 'RGB8'}, level -1 (FAST), tile encode + decode, rasters and blobs resident in HBM",
                        "batch": B, "tiles": len(tiles), "tiles_per_rank": t1 - t0, "share_px": my_px,
-                       "parallelism": f"tile-range x{world}" + (" + RCCL gatherv of blobs to rank 0" if world > 1 else ""),
+                       "parallelism": f"tile-range x{world}" + (f" + gatherv of blobs to rank 0 ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
                        "compressed_bytes": int(sum(lens))},
             "verified": verified,
             "single_image_encode_mpx_s": round(my_px / enc_ms / 1e3, 1), "single_image_decode_mpx_s": round(my_px / dec_ms / 1e3, 1),

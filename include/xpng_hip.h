@@ -53,6 +53,10 @@ int xpnghip_ctx_create(xpnghip_ctx **ctx, int device, uint64_t w, uint64_t h, in
  * (tile, stream), so a single 4096^2 image (81 tiles) cannot fill 256 CUs; a batched launch runs the chains of all
  * images side by side (virtual tile = image * N + tile) at the latency of one image. */
 int xpnghip_ctx_create_batch(xpnghip_ctx **ctx, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch);
+/* Same, with workspace for tiles [r0, r1) only: a rank that codes one tile range of a large raster (multi-GPU sharding)
+ * pays HBM for its share, not for the whole image.  Encode / decode calls must stay inside [r0, r1). */
+int xpnghip_ctx_create_range(xpnghip_ctx **ctx, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch,
+                             uint64_t r0, uint64_t r1);
 uint32_t xpnghip_ctx_batch(const xpnghip_ctx *ctx);
 void xpnghip_ctx_destroy(xpnghip_ctx *ctx);
 uint64_t xpnghip_ctx_tile_count(const xpnghip_ctx *ctx);

@@ -64,6 +64,56 @@ def test_two_rank_gather_equals_single_process_encode():
     assert got == whole and sum(lens) == len(whole) and len(lens) == 2
 
 
+def _worker_batch(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    from xpng_amd.shard import gather_blobs_batch, tile_table, weighted_tile_ranges
+    from xpng_amd.synth import synth_raster
+    W, H, B = 1000, 900, 2
+    tiles = tile_table(W, H)
+    t0, t1 = weighted_tile_ranges(tiles, world)[rank]
+    bufs, lens = [], []
+    for b in range(B):
+        full = synth_raster("photo", W, H, True, seed=b + 1)
+        blob = b"".join(po.encode_tile(1, full, t) for t in tiles[t0:t1])
+        bufs.append(torch.from_numpy(np.frombuffer(blob + b"\0" * 32, np.uint8).copy()))
+        lens.append(len(blob))
+    outs, table = gather_blobs_batch(bufs, lens)
+    if rank == 0:
+        q.put(([o.numpy().tobytes() for o in outs], table))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_batched_gather():
+    from oracle import pyoracle as po
+    from xpng_amd.synth import synth_raster
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_batch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, table = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for b in range(2):
+        assert got[b] == po.encode_tiles(1, synth_raster("photo", 1000, 900, True, seed=b + 1))
+    assert len(table) == 2 and len(table[0]) == 2
+
+
+def test_host_tile_table_matches_oracle():
+    from oracle import pyoracle as po
+    from xpng_amd.shard import tile_table
+    for (w, h) in [(1, 1), (444, 444), (445, 444), (100, 2000), (2000, 100), (667, 667), (889, 445), (4096, 4096), (16384, 16384),
+                   (16384, 8192), (1334, 265), (3799, 1927), (300, 4000)]:
+        assert tile_table(w, h) == po.tile_table(w, h, 4), (w, h)
+
+
 def test_ranges_cover_all_tiles_once():
     from xpng_amd.shard import band_rows, tile_ranges, weighted_tile_ranges
     from oracle import pyoracle as po

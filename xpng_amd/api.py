@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "xpnghip_ctx_tile", "xpnghip_ctx_blob_bound", "xpnghip_ctx_workspace_bytes", "xpnghip_encode_device",
     "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
     "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
-    "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch",
+    "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -65,6 +65,8 @@ def hip_lib():
         L.xpnghip_ctx_create.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int]
         L.xpnghip_ctx_create_batch.restype = C.c_int
         L.xpnghip_ctx_create_batch.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int, C.c_uint32]
+        L.xpnghip_ctx_create_range.restype = C.c_int
+        L.xpnghip_ctx_create_range.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int, C.c_uint32, u64, u64]
         L.xpnghip_ctx_batch.restype = C.c_uint32
         L.xpnghip_ctx_batch.argtypes = [vp]
         L.xpnghip_encode_device_batch.restype = C.c_int
@@ -173,11 +175,12 @@ class Context:
 
     FETCH = {"pr": 0, "nl": 1, "r": 2, "g": 3, "b": 4, "a": 5, "k": 19, "sums": 30}
 
-    def __init__(self, w: int, h: int, pxsz: int, device: int = 0, batch: int = 1):
+    def __init__(self, w: int, h: int, pxsz: int, device: int = 0, batch: int = 1, tile_range=None):
         self.w, self.h, self.pxsz, self.device, self.batch = w, h, pxsz, device, batch
         self._h = C.c_void_p()
-        if hip_lib().xpnghip_ctx_create_batch(C.byref(self._h), device, w, h, pxsz, batch):
-            raise XpngError("xpnghip_ctx_create_batch: " + _err())
+        r0, r1 = tile_range if tile_range else (0, (1 << 64) - 1)
+        if hip_lib().xpnghip_ctx_create_range(C.byref(self._h), device, w, h, pxsz, batch, r0, r1):
+            raise XpngError("xpnghip_ctx_create_range: " + _err())
         self.n_tiles = hip_lib().xpnghip_ctx_tile_count(self._h)
 
     def close(self):

@@ -44,7 +44,9 @@ static void split_axis(uint64_t len, uint64_t base, uint64_t &count, uint64_t &f
     count = len / base; first = base + rem; second = base;
     if (rem > base / 2) { count++; second = first / 2; first = second + (first & 1); }
 }
-static void build_tiles(uint64_t W, uint64_t H, std::vector<TileDesc> &out) {
+// Tiles outside [r0, r1) get no plane / scratch space (a rank that encodes only its tile range of a large raster should
+// not pay HBM for the rest); such a context can only be used on sub-ranges of [r0, r1).
+static void build_tiles(uint64_t W, uint64_t H, std::vector<TileDesc> &out, uint64_t r0 = 0, uint64_t r1 = ~0ull) {
     uint64_t nx = 1, ny = 1, w0 = W, w1 = 0, bw = 0, h0 = H, h1 = 0, bh = 0;
     if (W * H > TILE_AREA) {
         if (W < 444) { bw = W; bh = TILE_AREA / W; }
@@ -65,8 +67,8 @@ static void build_tiles(uint64_t W, uint64_t H, std::vector<TileDesc> &out) {
             t.y = (uint32_t)y; t.h = (uint32_t)th;
             t.n = t.w * t.h;
             t.pbase = pbase; t.sbase = sbase;
-            pbase += rup(t.n + 64, 256);
-            sbase += tile_scratch_bytes(t.n);
+            const uint64_t idx = out.size();
+            if (idx >= r0 && idx < r1) { pbase += rup(t.n + 64, 256); sbase += tile_scratch_bytes(t.n); }
             out.push_back(t);
         }
     }
@@ -77,6 +79,7 @@ struct xpnghip_ctx {
     uint64_t W = 0, H = 0;
     int pxsz = 0;
     uint32_t B = 1;    // images per launch (native batching: virtual tile = image * N + tile)
+    uint64_t r0 = 0, r1 = 0;  // tile range this context has workspace for
     uint32_t spt = 0;  // streams per tile: 9 (+1 alpha)
     std::vector<TileDesc> tiles;  // the N tiles of ONE image (host copy); the device table has B * N entries
     uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
@@ -121,15 +124,17 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     delete c;
 }
 
-extern "C" int xpnghip_ctx_create_batch(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch) {
-    if (!out || !w || !h || w > (1u << 24) || h > (1u << 24) || (pxsz != 3 && pxsz != 4) || batch < 1 || batch > 4096) return fail("bad arguments");
+extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch,
+                                        uint64_t r0, uint64_t r1) {
+    if (!out || !w || !h || w > (1u << 24) || h > (1u << 24) || (pxsz != 3 && pxsz != 4) || batch < 1 || batch > 4096 || r0 >= r1) return fail("bad arguments");
     if (xpnghip_device_count() <= device || device < 0) return fail("no such HIP device (libxpng_hip has no CPU fallback)");
     HIPCHK(hipSetDevice(device));
     xpnghip_ctx *c = new xpnghip_ctx();
     c->device = device; c->W = w; c->H = h; c->pxsz = pxsz; c->spt = pxsz == 4 ? 10 : 9; c->B = batch;
-    build_tiles(w, h, c->tiles);
+    build_tiles(w, h, c->tiles, r0, r1);
     const uint64_t N = c->tiles.size(), VN = N * batch;
-    const TileDesc &last = c->tiles.back();
+    c->r0 = r0; c->r1 = r1 < N ? r1 : N;
+    const TileDesc &last = c->tiles[c->r1 - 1];
     c->plane_img = last.pbase + rup(last.n + 64, 256);
     c->scratch_img = last.sbase + tile_scratch_bytes(last.n);
     c->plane_stride = c->plane_img * batch;
@@ -175,8 +180,11 @@ extern "C" int xpnghip_ctx_create_batch(xpnghip_ctx **out, int device, uint64_t 
     *out = c;
     return 0;
 }
+extern "C" int xpnghip_ctx_create_batch(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch) {
+    return xpnghip_ctx_create_range(out, device, w, h, pxsz, batch, 0, ~0ull);
+}
 extern "C" int xpnghip_ctx_create(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz) {
-    return xpnghip_ctx_create_batch(out, device, w, h, pxsz, 1);
+    return xpnghip_ctx_create_range(out, device, w, h, pxsz, 1, 0, ~0ull);
 }
 
 extern "C" uint64_t xpnghip_ctx_tile_count(const xpnghip_ctx *c) { return c ? c->tiles.size() : 0; }
@@ -196,6 +204,7 @@ extern "C" uint64_t xpnghip_ctx_workspace_bytes(const xpnghip_ctx *c) { return c
 static int check_range(const xpnghip_ctx *c, uint64_t t0, uint64_t t1) {
     if (!c) return fail("null context");
     if (t0 >= t1 || t1 > c->tiles.size()) return fail("bad tile range");
+    if (t0 < c->r0 || t1 > c->r1) return fail("tile range outside the range this context was created for");
     return 0;
 }
 
@@ -265,7 +274,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * PXSZ;
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
     k_m1_streams<PXSZ><<<total, ST_THREADS, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    if (getenv("XPNG_NARROW_RANS")) {  // one wave per (tile, stream): lowest single-image latency path kept for A/B runs
+    if (getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"))) {
+        // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
         k_rans2_prep<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
@@ -285,7 +295,7 @@ static int ensure_m2(xpnghip_ctx *c) {
     const uint64_t N = c->tiles.size(), VN = N * c->B;
     std::vector<uint64_t> sb(VN);
     uint64_t o = 0;
-    for (uint64_t v = 0; v < VN; v++) { sb[v] = o; o += m2_tile_scratch(c->tiles[v % N].n); }
+    for (uint64_t v = 0; v < VN; v++) { sb[v] = o; if (v % N >= c->r0 && v % N < c->r1) o += m2_tile_scratch(c->tiles[v % N].n); }
     if (hipMalloc((void **)&c->d_scratch2, o + 8192) != hipSuccess || hipMalloc((void **)&c->d_sbase2, VN * 8) != hipSuccess ||
         hipMalloc((void **)&c->d_flags2, VN * 4) != hipSuccess || hipMalloc((void **)&c->d_stream_n2, VN * M2_SLOTS * 4) != hipSuccess ||
         hipMalloc((void **)&c->d_blk2, VN * M2_SLOTS * sizeof(M2Blk)) != hipSuccess || hipMalloc((void **)&c->d_mt2, VN * sizeof(M2Tile)) != hipSuccess ||

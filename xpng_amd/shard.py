@@ -11,6 +11,41 @@ from __future__ import annotations
 from typing import List, Sequence, Tuple
 
 
+TILE_AREA = 444 * 444
+
+
+def tile_table(W: int, H: int) -> List[Tuple[int, int, int, int]]:
+    """(x, y, w, h) of every tile in row-major order: the reference's compute_props_of_each_tile (libxpng.c:51-83), needed
+    on the host to choose a rank's tile range before any device context exists."""
+    def split(length, base):
+        n, rem = divmod(length, base)
+        first, second = base + rem, base
+        if rem > base // 2:
+            n += 1
+            second = first // 2
+            first = second + (first & 1)
+        return n, first, second
+    if W * H <= TILE_AREA:
+        return [(0, 0, W, H)]
+    if W < 444:
+        bw, bh = W, TILE_AREA // W
+    elif H < 444:
+        bh, bw = H, TILE_AREA // H
+    else:
+        bw = bh = 444
+    nx, w0, w1 = split(W, bw)
+    ny, h0, h1 = split(H, bh)
+    out = []
+    for j in range(ny):
+        y = 0 if j == 0 else (h0 if j == 1 else h0 + h1 + (j - 2) * bh)
+        th = h0 if j == 0 else (h1 if j == 1 else bh)
+        for i in range(nx):
+            x = 0 if i == 0 else (w0 if i == 1 else w0 + w1 + (i - 2) * bw)
+            tw = w0 if i == 0 else (w1 if i == 1 else bw)
+            out.append((x, y, tw, th))
+    return out
+
+
 def tile_ranges(n_tiles: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous ranges [floor(k*T/G), floor((k+1)*T/G))."""
     return [(k * n_tiles // world, (k + 1) * n_tiles // world) for k in range(world)]
@@ -73,5 +108,48 @@ def gather_blobs(local, local_len: int, group=None, dst: int = 0):
         return out, lens
     if local_len:
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_len].contiguous(), dst, group)]):
+            req.wait()
+    return None, lens
+
+
+def gather_blobs_batch(locals_, lens_local, group=None, dst: int = 0):
+    """gatherv for a batch: every rank holds B blob buffers (one per image) with lens_local[b] valid bytes each.  One
+    all-gather of the B lengths per rank, then ONE grouped send/recv moves every rank's B blobs to rank `dst`, which returns
+    a list of B tensors (image b = rank-ordered concatenation of its tile ranges) and the (world x B) length table."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = len(locals_)
+    dev = locals_[0].device
+    mine = torch.tensor(list(lens_local), dtype=torch.int64, device=dev)
+    table = torch.zeros(world * B, dtype=torch.int64, device=dev)
+    if dev.type == "cuda":
+        dist.all_gather_into_tensor(table, mine, group=group)
+    else:
+        dist.all_gather(list(table.split(B)), mine, group=group)
+    lens = [[int(v) for v in row] for row in table.view(world, B).tolist()]
+    if world == 1:
+        return [locals_[b][:lens_local[b]] for b in range(B)], lens
+    if rank == dst:
+        outs, ops = [], []
+        for b in range(B):
+            out = torch.empty(sum(lens[r][b] for r in range(world)), dtype=torch.uint8, device=dev)
+            o = 0
+            for r in range(world):
+                seg = out[o:o + lens[r][b]]
+                if r == dst:
+                    seg.copy_(locals_[b][:lens[r][b]])
+                elif lens[r][b]:
+                    ops.append(dist.P2POp(dist.irecv, seg, r, group))
+                o += lens[r][b]
+            outs.append(out)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return outs, lens
+    ops = [dist.P2POp(dist.isend, locals_[b][:lens_local[b]], dst, group) for b in range(B) if lens_local[b]]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
             req.wait()
     return None, lens
