@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--roofline-reps", type=int, default=50)
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="contexts (each with its own HIP stream and buffers) that consecutive steps alternate between, so the "
+                         "encode of step k+1 runs beside the decode of step k; 1 = strictly serial steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")
     ap.add_argument("--batch", type=int, default=64,
                     help="images per launch per rank: a step encodes+decodes `batch` rasters of the workload in one batched launch "
@@ -163,6 +166,15 @@ def main():
     rast_ptrs = [d_raster_virtual] * B  # the same synthetic raster, encoded B times into B separate outputs
     blob_ptrs = [t.data_ptr() for t in d_blobs_all]
     back_ptrs = [t.data_ptr() - y0 * bpr for t in d_back_all]
+    # pipeline slots: slot 0 is (ctx, current stream, the buffers above); further slots get their own context / stream / buffers
+    P = max(1, args.pipeline)
+    slots = [dict(ctx=ctx, stream=torch.cuda.current_stream(), blobs=d_blobs_all, back=d_back_all, blob_ptrs=blob_ptrs, back_ptrs=back_ptrs)]
+    for _ in range(P - 1):
+        bl = [torch.empty_like(d_blobs_all[0]) for _ in range(B)]
+        bk = [torch.zeros_like(band) for _ in range(B)]
+        slots.append(dict(ctx=xpng_amd.Context(W, H, ch, device=local_rank, batch=B, tile_range=(t0, t1)), stream=torch.cuda.Stream(),
+                          blobs=bl, back=bk, blob_ptrs=[t.data_ptr() for t in bl], back_ptrs=[t.data_ptr() - y0 * bpr for t in bk]))
+    step_no = [0]
     my_px = sum(t[2] * t[3] for t in tiles[t0:t1])
     total_px = W * H
 
@@ -180,10 +192,11 @@ def main():
     verified = {"roundtrip": bool(ok)}
     use_host = world > 1 and args.backend != "nccl"
 
-    def exchange():  # the one exchange of the path: every rank's B blobs -> rank 0 (RCCL send/recv; no collective on the data path)
+    def exchange(bufs=None):  # the one exchange of the path: every rank's B blobs -> rank 0 (RCCL send/recv; no collective on the data path)
+        bufs = d_blobs_all if bufs is None else bufs
         if not use_host:
-            return gather_blobs_batch(d_blobs_all, [n] * B)
-        outs, table = gather_blobs_batch([t[:n].cpu() for t in d_blobs_all], [n] * B)
+            return gather_blobs_batch(bufs, [n] * B)
+        outs, table = gather_blobs_batch([t[:n].cpu() for t in bufs], [n] * B)
         return outs, table
 
     if world > 1:
@@ -207,11 +220,15 @@ def main():
         raise SystemExit(f"rank {rank}: output is NOT bit-exact / does not round-trip: {verified}")
 
     def step():
-        # one launch sequence covers all B images (virtual tile = image * N + tile)
-        ctx.encode_device_batch(1, rast_ptrs, blob_ptrs, t0, t1, stream=stream, sync=False)
+        # one launch sequence covers all B images (virtual tile = image * N + tile); consecutive steps alternate pipeline slots
+        sl = slots[step_no[0] % P]
+        step_no[0] += 1
+        sh = sl["stream"].cuda_stream
+        sl["ctx"].encode_device_batch(1, rast_ptrs, sl["blob_ptrs"], t0, t1, stream=sh, sync=False)
         if world > 1:
-            exchange()  # tile bytes are deterministic: n is the length verified above
-        ctx.decode_device_batch(1, blob_ptrs, [off] * B, back_ptrs, t0, t1, stream=stream)
+            with torch.cuda.stream(sl["stream"]):
+                exchange(sl["blobs"])  # tile bytes are deterministic: n is the length verified above
+        sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], [off] * B, sl["back_ptrs"], t0, t1, stream=sh)
 
     def barrier():
         torch.cuda.synchronize()
@@ -232,10 +249,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # every image of the batch must have produced the verified bytes and raster
-    for bi in range(1, B):
-        if ctx_len_at(ctx, bi) != n or not torch.equal(d_blobs_all[bi][:n], d_blobs_all[0][:n]) or not torch.equal(d_back_all[bi], d_back_all[0]):
-            raise SystemExit(f"rank {rank}: batch image {bi} differs from image 0")
+    # every image of every pipeline slot must have produced the verified bytes and raster
+    for si, sl in enumerate(slots):
+        for bi in range(B):
+            if ctx_len_at(sl["ctx"], bi) != n or not torch.equal(sl["blobs"][bi][:n], d_blobs_all[0][:n]) or not torch.equal(sl["back"][bi], d_back_all[0]):
+                raise SystemExit(f"rank {rank}: slot {si} image {bi} differs from the verified image")
 
     # ---- per-stage rates on this rank (HIP events on the stream the kernels run on)
     def timed(fn, reps):
@@ -264,7 +282,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' {'RGBA8' if alpha else 'RGB8'}, level -1 (FAST), tile encode + decode, rasters and blobs resident in HBM",
-                       "batch": B, "tiles": len(tiles), "tiles_per_rank": t1 - t0, "share_px": my_px,
+                       "batch": B, "pipeline_slots": P, "tiles": len(tiles), "tiles_per_rank": t1 - t0, "share_px": my_px,
                        "parallelism": f"tile-range x{world}" + (f" + gatherv of blobs to rank 0 ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
                        "compressed_bytes": int(sum(lens))},
             "verified": verified,
@@ -285,7 +303,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for sl in slots:
+        sl["ctx"].close()
 
 
 if __name__ == "__main__":

@@ -153,8 +153,8 @@ __device__ __forceinline__ uint32_t swar_zigzag8(uint32_t d) {  // per byte: v =
     return ((d << 1) & 0xFEFEFEFEu) ^ ((sgn << 8) - sgn);
 }
 // interior pixel (row > 0, column > 0): returns the zig-zag word (zr | zg<<8 | zb<<16 | za<<24) and nl.
-__device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, int useGrad, int useG,
-                                                      uint32_t &nl) {
+template <int useGrad, int useG>
+__device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, uint32_t &nl) {
     uint32_t pred;
     if (!useGrad) {
         pred = __builtin_amdgcn_lerp(L, U, 0x01010101u);  // per byte (L + U + 1) >> 1   (p2a)
@@ -179,6 +179,88 @@ __device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, 
     return z;
 }
 
+constexpr uint32_t TR_ROWS = 16, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
+// phase 2 of k_m1_transform_rgba, specialised on the tile's predictor flags so that no per-pixel branch on them remains
+template <int useGrad, int useG>
+__device__ __forceinline__ void transform_phase2(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first,
+                                                 uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride) {
+    const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
+    // (row, column) of a thread's first group by one division, then advanced incrementally: +1024 pixels per iteration
+    uint32_t yy = (threadIdx.x * 4) / t.w, x0 = threadIdx.x * 4 - yy * t.w;
+    const uint32_t dy = 1024 / t.w, dx = 1024 - dy * t.w;
+    for (uint32_t g = threadIdx.x; g < groups; g += 256, yy += dy, x0 += dx) {
+        if (x0 >= t.w) { x0 -= t.w; yy++; }
+        const uint32_t j0 = g * 4;  // pixel index inside the strip
+        uint32_t x = x0;
+        uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
+        const uint32_t lr = yy + (y0 - first);  // LDS row of pixel row yy
+        const uint32_t sh = (uint32_t)(((uint64_t)(t.y + first + lr) * bpr + (uint64_t)t.x * 4) & 15);
+        const uint32_t *rowc = reinterpret_cast<const uint32_t *>(rows + lr * TR_PITCH + sh);
+        if (x + 3 < t.w && j0 + 3 < strip_px && (bpr & 15) == 0) {
+            // whole group in one row (and every row has the same 16-byte phase): 5 + 5 dwords
+            const uint32_t *rowu = reinterpret_cast<const uint32_t *>(rows + (lr ? lr - 1 : 0) * TR_PITCH + sh);
+            const bool row0 = (y0 + yy) == 0;
+            uint32_t c[5], u[5];
+            c[0] = x ? rowc[x - 1] : 0u;
+            u[0] = (x && !row0) ? rowu[x - 1] : 0u;
+            if (sh == 0) {  // 16-byte aligned group: one ds_read_b128 per row (dword reads at a 16-byte lane stride are 4-way bank conflicts)
+                const uint4 cc = *reinterpret_cast<const uint4 *>(rowc + x);
+                const uint4 uu = row0 ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(rowu + x);
+                c[1] = cc.x; c[2] = cc.y; c[3] = cc.z; c[4] = cc.w;
+                u[1] = uu.x; u[2] = uu.y; u[3] = uu.z; u[4] = uu.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { c[k + 1] = rowc[x + k]; u[k + 1] = row0 ? 0u : rowu[x + k]; }
+            }
+            if (!row0 && x > 0) {  // interior group: byte-parallel arithmetic, then a 4x4 byte transpose into the planes
+                uint32_t z[4], n4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior<useGrad, useG>(c[k + 1], c[k], u[k + 1], u[k], n4[k]);
+                onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
+                const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);  // z0.b0 z1.b0 z0.b1 z1.b1
+                const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);  // z0.b2 z1.b2 z0.b3 z1.b3
+                const uint32_t t23lo = __builtin_amdgcn_perm(z[3], z[2], 0x05010400u);
+                const uint32_t t23hi = __builtin_amdgcn_perm(z[3], z[2], 0x07030602u);
+                orr = __builtin_amdgcn_perm(t23lo, t01lo, 0x05040100u);  // b0 of z0..z3
+                og = __builtin_amdgcn_perm(t23lo, t01lo, 0x07060302u);   // b1
+                ob = __builtin_amdgcn_perm(t23hi, t01hi, 0x05040100u);   // b2
+                oa = __builtin_amdgcn_perm(t23hi, t01hi, 0x07060302u);   // b3
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+                    if (y0 + yy + x + k != 0) m1_pixel<4>(c[k + 1], c[k], u[k + 1], u[k], row0, x + k == 0, useGrad, useG, nl, zr, zg, zb, za);
+                    onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+                }
+            }
+        } else {
+            uint32_t y = yy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+                if (j0 + k < strip_px && (y0 + y + x) != 0) {
+                    const uint32_t l2 = y + (y0 - first);
+                    const uint32_t s2 = (uint32_t)(((uint64_t)(t.y + first + l2) * bpr + (uint64_t)t.x * 4) & 15);
+                    const uint32_t s1 = l2 ? (uint32_t)(((uint64_t)(t.y + first + l2 - 1) * bpr + (uint64_t)t.x * 4) & 15) : 0u;
+                    const uint32_t *rc = reinterpret_cast<const uint32_t *>(rows + l2 * TR_PITCH + s2);
+                    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rows + (l2 ? l2 - 1 : 0) * TR_PITCH + s1);
+                    const bool row0 = (y0 + y) == 0, col0 = x == 0;
+                    const uint32_t cur = rc[x], L = col0 ? 0u : rc[x - 1], U = row0 ? 0u : ru[x], UL = (row0 || col0) ? 0u : ru[x - 1];
+                    m1_pixel<4>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
+                }
+                onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+                if (++x == t.w) { x = 0; y++; }
+            }
+        }
+        const uint64_t o = t.pbase + (uint64_t)y0 * t.w + j0;
+        *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
+        *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
+        *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
+        *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
+        *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // K2 (fast form, RGBA)  LDS-staged per-pixel transform.  One 256-thread workgroup = a strip of TR_ROWS rows of one tile:
 //   phase 1  rows y0-1 .. y0+R-1 of the tile are copied global -> LDS with coalesced 16-byte loads (the halo row is the
@@ -188,7 +270,6 @@ __device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, 
 //            (10 dword reads per 4 pixels when the group sits in one row), the five symbol bytes of the 4 pixels are
 //            packed into one dword per plane and stored coalesced (256 B per wave instruction).
 // Tiles wider than TR_MAXW pixels (images narrower / flatter than 444 px) use the generic kernel.
-constexpr uint32_t TR_ROWS = 16, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
 
 __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                            uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
@@ -240,83 +321,12 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
         for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
     }
     __syncthreads();
-    // ---- phase 2
-    const int pr = pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h);
-    const int useGrad = (pr >> 1) & 1, useG = pr & 1;
-    const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
-    const float inv_w = 1.0f / (float)t.w;
-    for (uint32_t g = threadIdx.x; g < groups; g += 256) {
-        const uint32_t j0 = g * 4;  // pixel index inside the strip
-        uint32_t yy = (uint32_t)((float)j0 * inv_w);
-        if (yy * t.w > j0) yy--;
-        if ((yy + 1) * t.w <= j0) yy++;
-        uint32_t x = j0 - yy * t.w;
-        uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
-        const uint32_t lr = yy + (y0 - first);  // LDS row of pixel row yy
-        const uint32_t sh = (uint32_t)(((uint64_t)(t.y + first + lr) * bpr + (uint64_t)t.x * 4) & 15);
-        const uint32_t *rowc = reinterpret_cast<const uint32_t *>(rows + lr * TR_PITCH + sh);
-        if (x + 3 < t.w && j0 + 3 < strip_px && (bpr & 15) == 0) {
-            // whole group in one row (and every row has the same 16-byte phase): 5 + 5 dwords
-            const uint32_t *rowu = reinterpret_cast<const uint32_t *>(rows + (lr ? lr - 1 : 0) * TR_PITCH + sh);
-            const bool row0 = (y0 + yy) == 0;
-            uint32_t c[5], u[5];
-            c[0] = x ? rowc[x - 1] : 0u;
-            u[0] = (x && !row0) ? rowu[x - 1] : 0u;
-            if (sh == 0) {  // 16-byte aligned group: one ds_read_b128 per row (dword reads at a 16-byte lane stride are 4-way bank conflicts)
-                const uint4 cc = *reinterpret_cast<const uint4 *>(rowc + x);
-                const uint4 uu = row0 ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(rowu + x);
-                c[1] = cc.x; c[2] = cc.y; c[3] = cc.z; c[4] = cc.w;
-                u[1] = uu.x; u[2] = uu.y; u[3] = uu.z; u[4] = uu.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { c[k + 1] = rowc[x + k]; u[k + 1] = row0 ? 0u : rowu[x + k]; }
-            }
-            if (!row0 && x > 0) {  // interior group: byte-parallel arithmetic, then a 4x4 byte transpose into the planes
-                uint32_t z[4], n4[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior(c[k + 1], c[k], u[k + 1], u[k], useGrad, useG, n4[k]);
-                onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
-                const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);  // z0.b0 z1.b0 z0.b1 z1.b1
-                const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);  // z0.b2 z1.b2 z0.b3 z1.b3
-                const uint32_t t23lo = __builtin_amdgcn_perm(z[3], z[2], 0x05010400u);
-                const uint32_t t23hi = __builtin_amdgcn_perm(z[3], z[2], 0x07030602u);
-                orr = __builtin_amdgcn_perm(t23lo, t01lo, 0x05040100u);  // b0 of z0..z3
-                og = __builtin_amdgcn_perm(t23lo, t01lo, 0x07060302u);   // b1
-                ob = __builtin_amdgcn_perm(t23hi, t01hi, 0x05040100u);   // b2
-                oa = __builtin_amdgcn_perm(t23hi, t01hi, 0x07060302u);   // b3
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
-                    if (y0 + yy + x + k != 0) m1_pixel<4>(c[k + 1], c[k], u[k + 1], u[k], row0, x + k == 0, useGrad, useG, nl, zr, zg, zb, za);
-                    onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
-                }
-            }
-        } else {
-            uint32_t y = yy;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
-                if (j0 + k < strip_px && (y0 + y + x) != 0) {
-                    const uint32_t l2 = y + (y0 - first);
-                    const uint32_t s2 = (uint32_t)(((uint64_t)(t.y + first + l2) * bpr + (uint64_t)t.x * 4) & 15);
-                    const uint32_t s1 = l2 ? (uint32_t)(((uint64_t)(t.y + first + l2 - 1) * bpr + (uint64_t)t.x * 4) & 15) : 0u;
-                    const uint32_t *rc = reinterpret_cast<const uint32_t *>(rows + l2 * TR_PITCH + s2);
-                    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rows + (l2 ? l2 - 1 : 0) * TR_PITCH + s1);
-                    const bool row0 = (y0 + y) == 0, col0 = x == 0;
-                    const uint32_t cur = rc[x], L = col0 ? 0u : rc[x - 1], U = row0 ? 0u : ru[x], UL = (row0 || col0) ? 0u : ru[x - 1];
-                    m1_pixel<4>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
-                }
-                onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
-                if (++x == t.w) { x = 0; y++; }
-            }
-        }
-        const uint64_t o = t.pbase + (uint64_t)y0 * t.w + j0;
-        *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
-        *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
-        *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
-        *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
-        *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+    // ---- phase 2 (dispatch once per workgroup on the tile's predictor flags)
+    switch (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) {
+        case 0: transform_phase2<0, 0>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
+        case 1: transform_phase2<0, 1>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
+        case 2: transform_phase2<1, 0>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
+        default: transform_phase2<1, 1>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
     }
 }
 
