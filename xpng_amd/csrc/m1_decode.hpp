@@ -12,6 +12,7 @@
 //   k_dec_resid       bit cursor = scan of 3*nl; residual extraction from k; zig-zag / green add-back (804-813)
 //   k_dec_recon       causal prediction from reconstructed L/U/UL: anti-diagonal wavefront, one row per thread
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -497,7 +498,9 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ 
                 }
                 const uint32_t y = i / t.w, x = i - y * t.w;
                 if (useG && x > 0 && y > 0) { dr += dg; db += dg; }  // libxpng.c:813
-                word = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) | (1u << 24);
+                // top byte: "coded" marker = the pixel's alpha for RGBA (non-zero exactly when coded), 1 for RGB
+                word = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) |
+                       ((PXSZ == 4 ? (uint32_t)al[i] : 1u) << 24);
             }
             rs[i] = word;
         }
@@ -542,7 +545,7 @@ __device__ inline void recon_wavefront(const TileDesc &t, uint8_t *__restrict__ 
                 const uint32_t i = y * t.w + (uint32_t)x;
                 if (i == 0) outpx = first;
                 else {
-                    const bool coded = (rw >> 24) & 1;
+                    const bool coded = (rw >> 24) != 0;
                     if (coded) {
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
@@ -554,7 +557,7 @@ __device__ inline void recon_wavefront(const TileDesc &t, uint8_t *__restrict__ 
                             outpx |= (((rw >> (8 * c)) + (uint32_t)pred) & 255u) << (8 * c);
                         }
                     }
-                    if (PXSZ == 4) outpx |= (uint32_t)al[i] << 24;  // alpha==0 -> whole pixel 0 (libxpng.c:802)
+                    if (PXSZ == 4) outpx |= rw & 0xFF000000u;  // alpha travels in the residual word; alpha==0 -> whole pixel 0 (libxpng.c:802)
                 }
                 L = outpx;
                 uint8_t *o = dst + (uint64_t)y * bpr + (uint64_t)x * PXSZ;
@@ -572,11 +575,95 @@ __device__ inline void recon_wavefront(const TileDesc &t, uint8_t *__restrict__ 
     }
 }
 
+// Barrier-free form of the wavefront (tiles up to 1024 rows).  Wave w owns rows 64w..64w+63, lane l handles column s - l at
+// its own step s; no workgroup barrier: a wave only waits for the wave above through a progress counter in LDS.
+//   * U (row above, same column) is what lane l-1 produced one step earlier: one DPP wave_shr, no LDS;
+//   * lane 0 takes U from the boundary row of the wave above, which that wave's last lane streams into an LDS row buffer
+//     (64 columns are fetched at a time and handed out with v_readlane);
+//   * residual words are prefetched 4 steps ahead into rotating registers.
+// dynamic LDS: nw * ew dwords of boundary rows + 16 progress counters.
+template <int PXSZ>
+__device__ inline void recon_free(const TileDesc &t, uint8_t *__restrict__ dst, uint64_t bpr, const uint8_t *__restrict__ al,
+                                  const uint32_t *__restrict__ rs, uint32_t first, int predmode, uint32_t *edge, uint32_t ew,
+                                  uint32_t *prog) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t nw = (t.h + 63) >> 6;
+    if (tid < 16) prog[tid] = 0;
+    __syncthreads();
+    if (w >= nw) return;
+    const uint32_t y = 64 * w + lane;
+    const bool active = y < t.h;
+    const uint32_t *rsrow = rs + (uint64_t)(active ? y : 0) * t.w;
+    (void)al;
+    uint8_t *drow = dst + (uint64_t)(active ? y : 0) * bpr;
+    const uint32_t S = t.w + 63;  // steps of this wave
+    uint32_t *my_edge = edge + w * ew;
+    const uint32_t *up_edge = edge + (w ? w - 1 : 0) * ew;
+    const bool writer = lane == 63 && w + 1 < nw;  // (the last lane of a non-final wave is always an existing row)
+    uint32_t prev = 0, U = 0, UL = 0, ev = 0;
+    auto fetch = [&](uint32_t s) -> uint32_t {  // residual word this lane needs at step s
+        const int32_t x = (int32_t)s - (int32_t)lane;
+        return (active && x >= 0 && x < (int32_t)t.w) ? rsrow[x] : 0u;
+    };
+    uint32_t r0 = fetch(0), r1 = fetch(1), r2 = fetch(2), r3 = fetch(3);
+    auto step = [&](uint32_t s, uint32_t rw) {
+        if (w > 0 && (s & 63u) == 0 && s < t.w) {  // uniform: next 64 columns of the boundary row above
+            const uint32_t need = s + 64 < t.w ? s + 64 : t.w;
+            while (__hip_atomic_load(&prog[w - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+            ev = s + lane < t.w ? up_edge[s + lane] : 0u;
+        }
+        // previous-step output of the lane above (lane 0: boundary row of the wave above)
+        uint32_t Unew = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)prev, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)(s & 63u));
+        if (lane == 0) Unew = e0;
+        const int32_t x = (int32_t)s - (int32_t)lane;
+        const bool on = active && x >= 0 && x < (int32_t)t.w;
+        uint32_t outpx = 0;
+        if (on) {
+            UL = U; U = Unew;
+            const uint32_t i = y * t.w + (uint32_t)x;
+            if (i == 0) outpx = first;
+            else {
+                if ((rw >> 24) != 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int l = (prev >> (8 * c)) & 255, u = (U >> (8 * c)) & 255, ul = (UL >> (8 * c)) & 255;
+                        int pred;
+                        if (y == 0) pred = l;
+                        else if (x == 0) pred = u;
+                        else pred = predmode == 0 ? pred_avg(l, u) : predmode == 1 ? pred_grad(l, u, ul) : predmode == 2 ? l : u;
+                        outpx |= (((rw >> (8 * c)) + (uint32_t)pred) & 255u) << (8 * c);
+                    }
+                }
+                if (PXSZ == 4) outpx |= rw & 0xFF000000u;  // alpha travels in the residual word
+            }
+            uint8_t *o = drow + (uint64_t)x * PXSZ;
+            if (PXSZ == 4) *reinterpret_cast<uint32_t *>(o) = outpx;
+            else { o[0] = (uint8_t)outpx; o[1] = (uint8_t)(outpx >> 8); o[2] = (uint8_t)(outpx >> 16); }
+            if (writer) {
+                my_edge[x] = outpx;
+                if ((x & 15) == 15 || x + 1 == (int32_t)t.w) __hip_atomic_store(&prog[w], (uint32_t)x + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            prev = outpx;
+        }
+    };
+    uint32_t s = 0;
+    for (; s + 4 <= S; s += 4) {
+        uint32_t c0 = r0; r0 = fetch(s + 4); step(s, c0);
+        uint32_t c1 = r1; r1 = fetch(s + 5); step(s + 1, c1);
+        uint32_t c2 = r2; r2 = fetch(s + 6); step(s + 2, c2);
+        uint32_t c3 = r3; r3 = fetch(s + 7); step(s + 3, c3);
+    }
+    if (s < S) { step(s, r0); s++; }
+    if (s < S) { step(s, r1); s++; }
+    if (s < S) { step(s, r2); s++; }
+}
+
 template <int PXSZ>
 __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ info,
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint32_t *__restrict__ resid,
-                                                    uint8_t *const *__restrict__ rasters, uint64_t bpr) {
+                                                    uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t free_ew) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x;
     const DecTile d = info[j];
     const TileDesc t = tiles[vtile(sel, j)];
@@ -584,15 +671,20 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
     if (d.type == 0) {
         const uint8_t *src = d.blob + 4;
         const uint64_t row = (uint64_t)t.w * PXSZ;
-        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+        for (uint64_t b = tid; b < row * t.h; b += blockDim.x) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
         return;
     }
-    __shared__ uint32_t s_row[2][1024];
     // first pixel from the head of k (libxpng.c:850): bytes MSB-first
     const uint32_t kw0 = ld32u(d.blob + 8);
     uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16);
     if (PXSZ == 4) first |= (kw0 & 255u) << 24;
-    recon_wavefront<PXSZ>(t, dst, bpr, alpha + t.pbase, resid + t.pbase, first, (d.type >> 1) & 1, s_row);
+    if (free_ew) {
+        extern __shared__ uint32_t dyn_lds[];
+        recon_free<PXSZ>(t, dst, bpr, alpha + t.pbase, resid + t.pbase, first, (d.type >> 1) & 1, dyn_lds + 16, free_ew, dyn_lds);
+    } else {
+        __shared__ uint32_t s_row[2][1024];
+        recon_wavefront<PXSZ>(t, dst, bpr, alpha + t.pbase, resid + t.pbase, first, (d.type >> 1) & 1, s_row);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -621,8 +713,16 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
 
 // Launch the whole decode of tiles [t0, t1) of every image of the batch.  d_blob_ptrs / d_raster_ptrs are device arrays
 // of B pointers; tile_off holds B * cnt blob offsets (image-major), relative to each image's blob buffer.
+// geometry of the barrier-free reconstruction launch for tiles up to max_w x max_h (0 = use the barrier form)
+inline void recon_geometry(uint32_t max_w, uint32_t max_h, uint32_t &free_ew, uint32_t &threads, uint32_t &lds) {
+    const uint32_t nw = (max_h + 63) / 64;
+    free_ew = 0; threads = 1024; lds = 0;
+    if (getenv("XPNG_BARRIER_RECON") || max_h > 1024 || (uint64_t)nw * max_w * 4 + 64 > 60000) return;
+    free_ew = max_w; threads = nw * 64; lds = nw * max_w * 4 + 64;
+}
+
 inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
-                            int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
+                            uint32_t max_w, uint32_t max_h, int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr) {
     const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
     const TileSel sel{t0, cnt, (uint32_t)n_tiles};
@@ -630,6 +730,8 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     auto bad = [&](const char *m) { err = m; return 1; };
     if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err)) return 1;
     const uint64_t bpr = W * (uint64_t)pxsz;
+    uint32_t free_ew, rthreads, rlds;
+    recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
     if (!ws.side) {
         if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -651,10 +753,12 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         k_dec_resid<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr);
+        if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+        else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
         k_dec_resid<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr);
+        if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+        else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }
     if (hipGetLastError() != hipSuccess) return bad("decode kernel launch failed");
     return 0;

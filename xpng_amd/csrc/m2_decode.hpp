@@ -317,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_m2_dec_resid(const M2DecTile *__restri
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                        const uint32_t *__restrict__ resid, uint8_t *const *__restrict__ rasters,
-                                                       uint64_t bpr) {
+                                                       uint64_t bpr, uint32_t free_ew) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x;
     const M2DecTile d = info[j];
     const TileDesc t = tiles[vtile(sel, j)];
@@ -325,20 +325,19 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
     const uint64_t row = (uint64_t)t.w * 3;
     if (d.kind == 0) {  // raw rows (libxpng.c:941)
         const uint8_t *src = d.blob + 4;
-        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+        for (uint64_t b = tid; b < row * t.h; b += blockDim.x) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
         return;
     }
     if (d.kind == 4) {  // single colour (libxpng.c:916-927)
         const uint8_t *px = d.blob + 4;
-        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = px[o % 3]; }
+        for (uint64_t b = tid; b < row * t.h; b += blockDim.x) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = px[o % 3]; }
         return;
     }
     if (d.kind == 3) {  // raw gray (libxpng.c:875-878)
         const uint8_t *src = d.blob + 4;
-        for (uint64_t b = tid; b < row * t.h; b += 1024) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[y * t.w + o / 3]; }
+        for (uint64_t b = tid; b < row * t.h; b += blockDim.x) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[y * t.w + o / 3]; }
         return;
     }
-    __shared__ uint32_t s_row[2][1024];
     const uint32_t w0 = ld32u(d.blob + 8);  // head of b: first pixel, MSB first
     uint32_t first;
     int predmode;
@@ -350,11 +349,18 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
         first = ((w0 >> 24) & 255u) | (((w0 >> 16) & 255u) << 8) | (((w0 >> 8) & 255u) << 16);
         predmode = (d.m >> 1) & 1;
     }
-    recon_wavefront<3>(t, dst, bpr, nullptr, resid + t.pbase, first, predmode, s_row);
+    if (free_ew) {
+        extern __shared__ uint32_t dyn_lds[];
+        recon_free<3>(t, dst, bpr, nullptr, resid + t.pbase, first, predmode, dyn_lds + 16, free_ew, dyn_lds);
+    } else {
+        __shared__ uint32_t s_row[2][1024];
+        recon_wavefront<3>(t, dst, bpr, nullptr, resid + t.pbase, first, predmode, s_row);
+    }
 }
 
 // Launch the mode-2 decode of tiles [t0, t1) of every image of the batch (RGB only).
 inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
+                            uint32_t max_w, uint32_t max_h,
                             const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, M2DecTile *d_info2, M2Blk *d_blk2, uint16_t *d_tabs2, uint8_t *d_scratch2,
                             const uint64_t *d_sbase2, hipStream_t s, std::string &err) {
@@ -368,7 +374,9 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
     k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);
     k_m2_dec_resid<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
-    k_m2_dec_recon<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr);
+    uint32_t free_ew, rthreads, rlds;
+    recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
+    k_m2_dec_recon<<<total, rthreads, rlds, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, free_ew);
     if (hipGetLastError() != hipSuccess) { err = "mode-2 decode kernel launch failed"; return 1; }
     return 0;
 }
