@@ -228,7 +228,7 @@ def main():
         if world > 1:
             with torch.cuda.stream(sl["stream"]):
                 exchange(sl["blobs"])  # tile bytes are deterministic: n is the length verified above
-        sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], [off] * B, sl["back_ptrs"], t0, t1, stream=sh)
+        sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], [n] * B, [off] * B, sl["back_ptrs"], t0, t1, stream=sh)
 
     def barrier():
         torch.cuda.synchronize()

@@ -84,9 +84,14 @@ uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *ctx, uint32_t img);
 int xpnghip_decode_device(xpnghip_ctx *ctx, int mode, const void *d_blobs, uint64_t blobs_len,
                           const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream);
 
-/* Batched form: tile_off holds nimg * (t1 - t0) offsets, image-major, each relative to its image's blob buffer. */
-int xpnghip_decode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d_blobs, uint32_t nimg,
+/* Batched form: blobs_len[nimg] = bytes of each blob buffer; tile_off holds nimg * (t1 - t0) offsets, image-major, each
+ * relative to its image's blob buffer. */
+int xpnghip_decode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d_blobs, const uint64_t *blobs_len, uint32_t nimg,
                                 const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *const *d_rasters, void *stream);
+/* The reference decoder trusts the file; this one validates every tile header (lengths, offsets, symbol counts) on the
+ * device before using it.  Synchronises `stream` and returns 0 if the last decode accepted every tile, 1 if some tile
+ * was rejected (its pixels are left untouched), -1 on a HIP error.  xpnghip_decode_tiles checks it for you. */
+int xpnghip_ctx_decode_status(xpnghip_ctx *ctx, void *stream);
 
 /* Stage-only run for BASELINE config 2: predictor chooser + per-pixel transform (libxpng.c:92-140 and
  * the arithmetic of 497-519) over tiles [t0, t1); symbol planes stay in the context's workspace. */

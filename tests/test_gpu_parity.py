@@ -220,7 +220,7 @@ def test_batched_launch_equals_single_image_launches(gpu, po):
         assert blobs[i] == po.encode_tiles(1, rs[i]), i
     offs = [walk_tile_offsets(b, ctx.n_tiles)[0] for b in blobs]
     d_o = [torch.zeros(W * H * 4 + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
-    ctx.decode_device_batch(1, [t.data_ptr() for t in d_b], offs, [t.data_ptr() for t in d_o])
+    ctx.decode_device_batch(1, [t.data_ptr() for t in d_b], lens, offs, [t.data_ptr() for t in d_o])
     torch.cuda.synchronize()
     for i in range(B):
         assert np.array_equal(d_o[i][: W * H * 4].cpu().numpy().reshape(H, W, 4), rs[i]), i
@@ -249,3 +249,35 @@ def test_mode2_device_entry_points_match_oracle(gpu, po):
         torch.cuda.synchronize()
         assert np.array_equal(d_o[: h * w * 3].cpu().numpy().reshape(h, w, 3), raster), name
         ctx.close()
+
+
+def test_corrupt_files_are_rejected_not_executed(gpu, po, tmp_path):
+    """The reference decoder trusts the file (libxpng.c:982: no bounds checks).  On the GPU a wild offset is a device fault, so
+    every tile header is validated first: corrupt or truncated files make xpng_load fail cleanly, and good data still decodes."""
+    from xpng_amd.synth import synth_raster
+    rng = np.random.default_rng(5)
+    for alpha, level in ((True, 1), (False, 1), (False, 2)):
+        raster = synth_raster("photo", 700, 500, alpha)
+        good = po.encode_image(level, raster)
+        p = tmp_path / "x.xpng"
+        rejected = 0
+        for trial in range(24):
+            bad = bytearray(good)
+            if trial % 3 == 0:                      # truncate
+                bad = bad[: 8 + int(rng.integers(1, len(good) - 8))]
+            elif trial % 3 == 1:                    # smash a header-ish word near the start of a tile
+                o = 8 + int(rng.integers(0, 64))
+                bad[o:o + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            else:                                   # random words anywhere
+                for _ in range(8):
+                    o = int(rng.integers(8, len(bad) - 4))
+                    bad[o:o + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            p.write_bytes(bytes(bad))
+            try:
+                out = gpu.load(str(p))
+                assert out.shape == raster.shape   # accepted: payload corruption only changes pixel values, never faults
+            except gpu.XpngError:
+                rejected += 1
+        assert rejected >= 8
+        p.write_bytes(good)
+        assert np.array_equal(gpu.load(str(p)), raster)

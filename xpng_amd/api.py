@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "xpnghip_ctx_tile", "xpnghip_ctx_blob_bound", "xpnghip_ctx_workspace_bytes", "xpnghip_encode_device",
     "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
     "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
-    "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range",
+    "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range", "xpnghip_ctx_decode_status",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -74,7 +74,9 @@ def hip_lib():
         L.xpnghip_ctx_last_blobs_len_at.restype = u64
         L.xpnghip_ctx_last_blobs_len_at.argtypes = [vp, C.c_uint32]
         L.xpnghip_decode_device_batch.restype = C.c_int
-        L.xpnghip_decode_device_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.c_uint32, C.POINTER(u64), u64, u64, C.POINTER(vp), vp]
+        L.xpnghip_decode_device_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(u64), C.c_uint32, C.POINTER(u64), u64, u64, C.POINTER(vp), vp]
+        L.xpnghip_ctx_decode_status.restype = C.c_int
+        L.xpnghip_ctx_decode_status.argtypes = [vp, vp]
         L.xpnghip_ctx_destroy.restype = None
         L.xpnghip_ctx_destroy.argtypes = [vp]
         L.xpnghip_ctx_tile_count.restype = u64
@@ -228,8 +230,12 @@ class Context:
             raise XpngError("xpnghip_encode_device_batch: " + _err())
         return list(lens) if sync else None
 
-    def decode_device_batch(self, mode, d_blobs, tile_offs, d_rasters, t0=0, t1=None, stream=0):
-        """tile_offs: per image, the list of blob start offsets of tiles [t0, t1) inside that image's blob buffer."""
+    def decode_status(self, stream=0) -> int:
+        """Synchronise and report whether the last decode accepted every tile header (0) or rejected some (1)."""
+        return hip_lib().xpnghip_ctx_decode_status(self._h, stream)
+
+    def decode_device_batch(self, mode, d_blobs, blob_lens, tile_offs, d_rasters, t0=0, t1=None, stream=0):
+        """blob_lens: bytes of each blob buffer; tile_offs: per image, the blob start offsets of tiles [t0, t1)."""
         k = len(d_blobs)
         t1 = self.n_tiles if t1 is None else t1
         flat = [o for offs in tile_offs for o in offs]
@@ -237,8 +243,8 @@ class Context:
         key = (tuple(flat), t0, t1)
         if getattr(self, "_off_key", None) != key:
             self._off_key, self._off_arr = key, (C.c_uint64 * len(flat))(*flat)
-        ins, outs = (C.c_void_p * k)(*d_blobs), (C.c_void_p * k)(*d_rasters)
-        if hip_lib().xpnghip_decode_device_batch(self._h, mode, ins, k, self._off_arr, t0, t1, outs, stream):
+        ins, outs, lens = (C.c_void_p * k)(*d_blobs), (C.c_void_p * k)(*d_rasters), (C.c_uint64 * k)(*blob_lens)
+        if hip_lib().xpnghip_decode_device_batch(self._h, mode, ins, lens, k, self._off_arr, t0, t1, outs, stream):
             raise XpngError("xpnghip_decode_device_batch: " + _err())
 
     def last_blobs_len(self) -> int:

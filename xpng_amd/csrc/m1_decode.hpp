@@ -77,28 +77,62 @@ struct BitR {
 };
 
 // --------------------------------------------------------------------------------------------------
-__global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off, uint32_t cnt,
-                            uint32_t total, uint32_t spt, DecTile *__restrict__ info) {
+constexpr uint32_t TILE_BAD = 0xEE;  // type value of a tile whose headers failed validation: every kernel skips it
+
+// The reference decoder trusts the file ("no bounds checks on file contents"); on a GPU a wild
+// offset is a fault that can take the device down, so every length / offset / count is checked here, once, and a bad
+// tile is skipped (its pixels stay untouched) with bit 0 of *status set.
+__global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off,
+                            const uint64_t *__restrict__ blob_len, uint32_t cnt, uint32_t total, uint32_t spt, int pxsz,
+                            const TileDesc *__restrict__ tiles, TileSel sel, DecTile *__restrict__ info,
+                            uint32_t *__restrict__ status) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
+    const TileDesc t = tiles[vtile(sel, j)];
     DecTile d{};
     d.blob = blobs[j / cnt] + off[j];
+    const uint64_t avail = blob_len[j / cnt] > off[j] ? blob_len[j / cnt] - off[j] : 0;
     const uint8_t *f = d.blob;
-    const uint32_t h0 = ld32u(f);
-    d.type = h0 >> 24;
-    if (d.type != 0) {
-        const uint32_t ksz = ld32u(f + 4);  // includes itself (libxpng.c:556)
+    bool ok = avail >= 4;
+    uint32_t L = 0;
+    if (ok) {
+        const uint32_t h0 = ld32u(f);
+        d.type = h0 >> 24;
+        L = h0 & 0xFFFFFF;
+        ok = L <= avail;
+    }
+    if (ok && d.type == 0) ok = L == t.n * (uint32_t)pxsz + 4;
+    else if (ok) {
+        ok = L >= 12 && (d.type >> 4) == 1;
+        const uint32_t ksz = ok ? ld32u(f + 4) : 0;  // includes itself (libxpng.c:556)
+        ok = ok && ksz >= 8 && (ksz & 3) == 0 && 4 + (uint64_t)ksz <= L;
         d.kbytes = ksz - 4;
-        uint32_t o = 4 + ksz, acc = 0;
-        for (uint32_t c = 0; c < spt; c++) {
-            const uint32_t b0 = ld32u(f + o), ty = b0 >> 24;
-            d.blk_off[c] = o;
-            d.blk_n[c] = ty == 0 ? 0 : (ld32u(f + o + 4) & 0xFFFFFF);
-            if (c < 9) { d.ctx_start[c] = acc; acc += d.blk_n[c]; }
-            o += ty == 0 ? 4 : (b0 & 0xFFFFFF);
+        uint64_t o = 4 + (uint64_t)ksz;
+        uint32_t acc = 0;
+        for (uint32_t c = 0; c < spt && ok; c++) {
+            ok = o + 4 <= L;
+            if (!ok) break;
+            const uint32_t b0 = ld32u(f + o), ty = b0 >> 24, sz = ty == 0 ? 4 : (b0 & 0xFFFFFF);
+            ok = ty <= 4 && sz >= (ty == 0 ? 4u : 8u) && (sz & 3) == 0 && o + sz <= L;
+            if (!ok) break;
+            const uint32_t w1 = ty ? ld32u(f + o + 4) : 0, n = w1 & 0xFFFFFF, v2 = w1 >> 24;
+            if (ty == 2) ok = v2 >= 1 && v2 <= 8 && 8 + 4 * (((uint64_t)n * v2 + 31) >> 5) <= sz;
+            if (ty >= 3) {
+                ok = sz >= 28 + 4 && v2 <= 254;
+                if (ok) {
+                    const uint32_t h2 = ld32u(f + o + 8), toff = h2 & 0xFFFFFF, pb = h2 >> 24;
+                    ok = pb >= 10 && pb <= 15 && toff >= 5 && 8 + 4 * (uint64_t)toff < sz;
+                }
+            }
+            d.blk_off[c] = (uint32_t)o;
+            d.blk_n[c] = ty == 0 ? 0 : n;
+            if (c < 9) { d.ctx_start[c] = acc; acc += d.blk_n[c]; ok = ok && acc <= t.n - 1; }
+            else ok = ok && d.blk_n[c] <= t.n - 1;
+            o += sz;
         }
         d.ctx_start[9] = acc;
     }
+    if (!ok) { d.type = TILE_BAD; atomicOr(status, 1u); }
     info[j] = d;
 }
 
@@ -130,7 +164,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
     __shared__ uint8_t oring[512];
     const uint32_t j = blockIdx.x / c_count, c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63, par = lane & 1;
     const DecTile d = info[j];
-    if (d.type == 0) return;
+    if (d.type == 0 || d.type == TILE_BAD) return;
     const uint32_t vt = vtile(sel, j);
     const TileDesc t = tiles[vt];
     const uint8_t *in = d.blob + d.blk_off[c];
@@ -307,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ 
                                                     const uint8_t *__restrict__ asym, uint8_t *__restrict__ alpha) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DecTile d = info[j];
-    if (d.type == 0) return;
+    if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
     const uint8_t *sy = asym + t.pbase;  // sy[i-1] = symbol of pixel i
     uint8_t *al = alpha + t.pbase;
@@ -436,7 +470,7 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
                                                  uint8_t *__restrict__ nlseq) {
     const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
     const DecTile d = info[j];
-    if (d.type == 0) return;
+    if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
     const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ctx_start[9]);
     ctx_walk(ctxsym + t.pbase, lane < 9 ? d.ctx_start[lane] : 0, total, nlseq + t.pbase);
@@ -453,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ 
                                                     uint32_t *__restrict__ resid) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DecTile d = info[j];
-    if (d.type == 0) return;
+    if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
     const uint8_t *kbase = d.blob + 8, *kend = kbase + d.kbytes;
     const uint8_t *al = alpha + t.pbase, *nls = nlseq + t.pbase;
@@ -668,6 +702,7 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
     const DecTile d = info[j];
     const TileDesc t = tiles[vtile(sel, j)];
     uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
+    if (d.type == TILE_BAD) return;
     if (d.type == 0) {
         const uint8_t *src = d.blob + 4;
         const uint64_t row = (uint64_t)t.w * PXSZ;
@@ -722,7 +757,8 @@ inline void recon_geometry(uint32_t max_w, uint32_t max_h, uint32_t &free_ew, ui
 }
 
 inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
-                            uint32_t max_w, uint32_t max_h, int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
+                            uint32_t max_w, uint32_t max_h, int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *d_blob_len,
+                            uint32_t *d_status, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr) {
     const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
     const TileSel sel{t0, cnt, (uint32_t)n_tiles};
@@ -738,7 +774,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
             hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess)
             return bad("stream/event creation failed");
     }
-    k_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, cnt, total, spt, ws.d_info);
+    k_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, spt, pxsz, d_tiles, sel, ws.d_info, d_status);
     // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {

@@ -35,31 +35,49 @@ __device__ __forceinline__ uint32_t bits_at(const uint8_t *w, uint64_t pos, uint
     return (uint32_t)((two >> (64 - (pos & 31) - c)) & ((1ull << c) - 1));
 }
 
-__global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off, uint32_t cnt,
-                               uint32_t total, const TileDesc *__restrict__ tiles, TileSel sel, M2DecTile *__restrict__ info,
-                               M2Blk *__restrict__ blk, uint16_t *__restrict__ tabs) {
+constexpr uint32_t M2_KIND_BAD = 9;  // tile failed validation: every kernel skips it (see k_dec_parse in m1_decode.hpp)
+
+__global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off,
+                               const uint64_t *__restrict__ blob_len, uint32_t cnt, uint32_t total,
+                               const TileDesc *__restrict__ tiles, TileSel sel, M2DecTile *__restrict__ info,
+                               M2Blk *__restrict__ blk, uint16_t *__restrict__ tabs, uint32_t *__restrict__ status) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
     const uint32_t tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
     M2DecTile d{};
     d.blob = blobs[j / cnt] + off[j];
-    const uint32_t h0 = ld32u(d.blob), ty = h0 >> 24;
+    const uint64_t avail = blob_len[j / cnt] > off[j] ? blob_len[j / cnt] - off[j] : 0;
+    bool ok = avail >= 4;
+    const uint32_t h0 = ok ? ld32u(d.blob) : 0, ty = h0 >> 24, L = h0 & 0xFFFFFF;
+    ok = ok && L <= avail && L >= 8;
     M2Blk *mb = blk + (uint64_t)tile * M2_SLOTS;
-    if (ty == 0) d.kind = 0;
-    else if (ty == 255) d.kind = 4;
-    else if ((ty >> 4) == 2) { d.kind = (ty & 8) ? 3 : 2; d.m = ty & 3; }
-    else { d.kind = 1; d.m = ty & 3; }
-    if (d.kind == 1 || d.kind == 2) {
+    if (ty == 0) { d.kind = 0; ok = ok && L == 3 * t.n + 4; }
+    else if (ty == 255) { d.kind = 4; ok = ok && L == 8; }
+    else if ((ty >> 4) == 2) { d.kind = (ty & 8) ? 3 : 2; d.m = ty & 3; if (d.kind == 3) ok = ok && L == t.n + 4; }
+    else if ((ty >> 4) == 1) { d.kind = 1; d.m = ty & 3; }
+    else ok = false;
+    if (ok && (d.kind == 1 || d.kind == 2)) {
         d.bsz = ld32u(d.blob + 4);
+        ok = d.bsz >= 8 && (d.bsz & 3) == 0 && 4 + (uint64_t)d.bsz + 4 <= L;
+    }
+    if (ok && (d.kind == 1 || d.kind == 2)) {
         const uint8_t *bw = d.blob + 8;
         const uint64_t endbit = (uint64_t)(d.bsz - 4) * 8;
         uint64_t pos = d.kind == 1 ? 24 : 8;
         uint32_t o = 4 + d.bsz, coded = 0;
         const uint32_t s0 = d.kind == 1 ? 0 : 17, s1 = d.kind == 1 ? M2_STREAMS : 18;
-        for (uint32_t s = s0; s < s1; s++) {
+        for (uint32_t s = s0; s < s1 && ok; s++) {
             const uint32_t Nnom = m2_nominal(s), pb = s >= 17 ? 15 : 14, rawBits = (uint32_t)bit_width(Nnom - 1);
-            const uint32_t hdr = ld32u(d.blob + o), type = hdr >> 24, w1 = type ? ld32u(d.blob + o + 4) : 0;
+            ok = (uint64_t)o + 4 <= L;
+            if (!ok) break;
+            const uint32_t hdr = ld32u(d.blob + o), type = hdr >> 24, bsize = hdr & 0xFFFFFF;
+            ok = type <= 4 && bsize >= (type == 0 ? 4u : 8u) && (uint64_t)o + bsize <= L && (type < 3 || bsize >= 24);
+            if (!ok) break;
+            const uint32_t w1 = type ? ld32u(d.blob + o + 4) : 0;
+            const uint32_t ncap = (s >= 11 && s < 17) ? 3 * t.n : t.n;  // stream capacity (m2_off_stream layout)
+            ok = (type == 1 ? (w1 & 0xFFFFFF) : w1) <= ncap;
+            if (!ok) break;
             M2Blk r{type, 0, o, 0};
             if (type == 1) { r.n = w1 & 0xFFFFFF; r.pbits = w1 >> 24; }
             else if (type == 2) { r.n = w1; r.pbits = (uint32_t)pos; pos += (uint64_t)w1 * rawBits; }
@@ -79,8 +97,9 @@ __global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const u
             o += hdr & 0xFFFFFF;
         }
         d.coded = coded;
+        ok = ok && coded <= t.n - 1;
     }
-    (void)t;
+    if (!ok) { d.kind = M2_KIND_BAD; atomicOr(status, 1u); }
     info[j] = d;
 }
 
@@ -323,6 +342,7 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
     const TileDesc t = tiles[vtile(sel, j)];
     uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * 3;
     const uint64_t row = (uint64_t)t.w * 3;
+    if (d.kind == M2_KIND_BAD) return;
     if (d.kind == 0) {  // raw rows (libxpng.c:941)
         const uint8_t *src = d.blob + 4;
         for (uint64_t b = tid; b < row * t.h; b += blockDim.x) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
@@ -361,7 +381,8 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
 // Launch the mode-2 decode of tiles [t0, t1) of every image of the batch (RGB only).
 inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
                             uint32_t max_w, uint32_t max_h,
-                            const uint8_t *const *d_blob_ptrs, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
+                            const uint8_t *const *d_blob_ptrs, const uint64_t *d_blob_len, uint32_t *d_status,
+                            const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, M2DecTile *d_info2, M2Blk *d_blk2, uint16_t *d_tabs2, uint8_t *d_scratch2,
                             const uint64_t *d_sbase2, hipStream_t s, std::string &err) {
     const uint32_t cnt = t1 - t0, total = B * cnt;
@@ -369,7 +390,7 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err)) return 1;
     const uint64_t bpr = W * 3;
     if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }
-    k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2);
+    k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2, d_status);
     k_rans1_decode<14><<<total * M2_STREAMS, 64, 0, s>>>(d_info2, d_tiles, sel, 0, M2_STREAMS, d_blk2, d_tabs2, d_scratch2, d_sbase2);
     k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
     k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);

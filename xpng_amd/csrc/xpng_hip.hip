@@ -87,6 +87,9 @@ struct xpnghip_ctx {
     uint8_t *d_planes = nullptr, *d_scratch = nullptr;
     uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
     uint64_t *d_off = nullptr, *d_totals = nullptr, *d_dbg = nullptr;
+    uint64_t *d_blob_len = nullptr;       // decode: B blob lengths
+    uint32_t *d_status = nullptr;         // decode: bit 0 = some tile failed header validation
+    std::vector<uint64_t> h_blob_len;
     const uint8_t **d_in_ptrs = nullptr;  // B raster (encode) / blob (decode) pointers
     uint8_t **d_out_ptrs = nullptr;       // B blob (encode) / raster (decode) pointers
     std::vector<const void *> h_in_ptrs;  // what d_in_ptrs / d_out_ptrs currently hold (skip the upload when unchanged)
@@ -116,7 +119,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs,
-                    c->d_wprep, c->d_wtab, c->d_wF, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
+                    c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     decode_ws_free(c->dec);
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -168,6 +171,8 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
     ALLOC(c->d_wprep, VN * 10 * sizeof(WPrep));
     ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096);
     ALLOC(c->d_wF, VN * 10 * 512);
+    ALLOC(c->d_blob_len, (uint64_t)batch * 8);
+    ALLOC(c->d_status, 64);
     ALLOC(c->d_in_ptrs, (uint64_t)batch * 8);
     ALLOC(c->d_out_ptrs, (uint64_t)batch * 8);
 #undef ALLOC
@@ -359,7 +364,7 @@ extern "C" int xpnghip_encode_device(xpnghip_ctx *c, int mode, const void *d_ras
 extern "C" uint64_t xpnghip_ctx_last_blobs_len(xpnghip_ctx *c) { return c ? c->h_total[0] : 0; }
 extern "C" uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *c, uint32_t img) { return c && img < c->B ? c->h_total[img] : 0; }
 
-extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void *const *d_blobs, uint32_t nimg,
+extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void *const *d_blobs, const uint64_t *blobs_len, uint32_t nimg,
                                            const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *const *d_rasters, void *stream) {
     if (check_range(c, t0, t1)) return 1;
     if (mode != 1 && mode != 2) return fail("tile mode must be 1 or 2");
@@ -367,20 +372,36 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (set_ptrs(c, d_blobs, d_rasters, nimg, s)) return 1;
+    if (!blobs_len) return fail("blob lengths are required (tile headers are validated against them)");
+    if (c->h_blob_len.size() != nimg || memcmp(c->h_blob_len.data(), blobs_len, (size_t)nimg * 8) != 0) {
+        HIPCHK(hipMemcpyAsync(c->d_blob_len, blobs_len, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        c->h_blob_len.assign(blobs_len, blobs_len + nimg);
+    }
+    HIPCHK(hipMemsetAsync(c->d_status, 0, 4, s));
     uint32_t max_w = 0, max_h = 0;
     for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
-        return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->d_in_ptrs, tile_off, (uint32_t)t0,
+        return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->d_in_ptrs, c->d_blob_len, c->d_status, tile_off, (uint32_t)t0,
                                 (uint32_t)t1, c->d_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
     }
-    return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_in_ptrs, tile_off,
+    return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_in_ptrs, c->d_blob_len, c->d_status, tile_off,
                             (uint32_t)t0, (uint32_t)t1, c->d_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr);
 }
 extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
                                      const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
-    (void)blobs_len;
-    return xpnghip_decode_device_batch(c, mode, &d_blobs, 1, tile_off, t0, t1, &d_raster, stream);
+    return xpnghip_decode_device_batch(c, mode, &d_blobs, &blobs_len, 1, tile_off, t0, t1, &d_raster, stream);
+}
+// Synchronises `stream` and reports the last decode: 0 = every tile header was consistent, 1 = at least one tile was
+// rejected (its pixels were left untouched), -1 = HIP error.
+extern "C" int xpnghip_ctx_decode_status(xpnghip_ctx *c, void *stream) {
+    if (!c) return -1;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    uint32_t v = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+        hipMemcpy(&v, c->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)(v & 1);
 }
 
 // ---- host-buffer wrappers ------------------------------------------------------------------------------
@@ -431,9 +452,11 @@ extern "C" int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blo
     HIPCHK(hipMalloc((void **)&d_in, blobs_len + 64));
     int rc = 1;
     if (hipMemcpyAsync(d_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-        !xpnghip_decode_device(c, mode, d_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr) &&
-        hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(raster, c->d_raster, s, hipMemcpyDeviceToHost) == hipSuccess)
-        rc = 0;
+        !xpnghip_decode_device(c, mode, d_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr)) {
+        const int st = xpnghip_ctx_decode_status(c, nullptr);
+        if (st == 1) g_err = "corrupt file: a tile header is inconsistent with the tile table";
+        else if (st == 0 && hipMemcpy(raster, c->d_raster, s, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
     else if (g_err.empty()) g_err = "decode failed";
     (void)hipFree(d_in);
     return rc;
