@@ -22,6 +22,11 @@ import argparse
 import hashlib
 import json
 import os
+
+# Every pipeline slot drives three HIP streams (main, alpha-decode side branch, alpha-encode side branch).  The HIP
+# runtime maps streams onto 4 hardware queues by default, and streams that share a queue serialise; this must be set
+# before the runtime initialises (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import re
 import subprocess
 import sys
@@ -101,7 +106,7 @@ def main():
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--roofline-reps", type=int, default=50)
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts (each with its own HIP stream and buffers) that consecutive steps alternate between, so the "
                          "encode of step k+1 runs beside the decode of step k; 1 = strictly serial steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")

@@ -27,11 +27,15 @@ struct DecTile {  // per-tile parse result (device)
     uint32_t kbytes;    // bytes of k words
     uint32_t blk_off[10];  // block offsets relative to the blob start
     uint32_t blk_n[10];    // symbols per block
-    uint32_t ctx_start[10];  // start of context stream c inside the tile's symbol area (ctx_start[9] = total coded)
+    uint32_t ctx_start[10];  // 16-byte aligned start of context stream c inside the tile's symbol area (ctx_start[9] = total coded)
 };
+
+struct WDec;  // rans2_wide_dec.hpp
 
 struct DecodeWs {
     uint64_t cap_tiles = 0, cap_plane = 0;
+    WDec *d_wdec = nullptr;              // wide rANS decode: per (tile, stream) descriptors and decode tables
+    uint8_t *d_dtab = nullptr;
     std::vector<uint64_t> last_off;      // tile offsets already resident in d_off (skip the upload when unchanged)
     uint32_t last_t0 = 0;
     hipStream_t side = nullptr;          // alpha branch runs beside the nl-context branch
@@ -42,7 +46,7 @@ struct DecodeWs {
     uint32_t *d_resid = nullptr;
 };
 inline void decode_ws_free(DecodeWs &w) {
-    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid};
+    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid, w.d_wdec, w.d_dtab};
     for (void *q : p) if (q) (void)hipFree(q);
     if (w.side) (void)hipStreamDestroy(w.side);
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
@@ -108,7 +112,7 @@ __global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint
         ok = ok && ksz >= 8 && (ksz & 3) == 0 && 4 + (uint64_t)ksz <= L;
         d.kbytes = ksz - 4;
         uint64_t o = 4 + (uint64_t)ksz;
-        uint32_t acc = 0;
+        uint32_t acc = 0, coded = 0;  // acc: 16-byte aligned start of the next context stream inside the tile's symbol area
         for (uint32_t c = 0; c < spt && ok; c++) {
             ok = o + 4 <= L;
             if (!ok) break;
@@ -126,15 +130,19 @@ __global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint
             }
             d.blk_off[c] = (uint32_t)o;
             d.blk_n[c] = ty == 0 ? 0 : n;
-            if (c < 9) { d.ctx_start[c] = acc; acc += d.blk_n[c]; ok = ok && acc <= t.n - 1; }
+            if (c < 9) { d.ctx_start[c] = acc; acc = (acc + d.blk_n[c] + 15u) & ~15u; coded += d.blk_n[c]; ok = ok && coded <= t.n - 1; }
             else ok = ok && d.blk_n[c] <= t.n - 1;
             o += sz;
         }
-        d.ctx_start[9] = acc;
+        d.ctx_start[9] = coded;
     }
     if (!ok) { d.type = TILE_BAD; atomicOr(status, 1u); }
     info[j] = d;
 }
+
+}  // namespace xpng
+#include "rans2_wide_dec.hpp"
+namespace xpng {
 
 // --------------------------------------------------------------------------------------------------
 // one v2 block -> symbols (decompress_block_v2, libxpng.c:429-493).  Single-wave workgroup per (tile, stream).
@@ -732,7 +740,9 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
         if (hipMalloc((void **)&ws.d_info, (uint64_t)B * n_tiles * sizeof(DecTile)) != hipSuccess || hipMalloc((void **)&ws.d_off, (uint64_t)B * n_tiles * 8) != hipSuccess ||
             hipMalloc((void **)&ws.d_ctxsym, plane + 8192) != hipSuccess || hipMalloc((void **)&ws.d_asym, plane + 64) != hipSuccess ||
             hipMalloc((void **)&ws.d_alpha, plane + 64) != hipSuccess || hipMalloc((void **)&ws.d_nlseq, plane + 64) != hipSuccess ||
-            hipMalloc((void **)&ws.d_resid, 4 * plane + 64) != hipSuccess)
+            hipMalloc((void **)&ws.d_resid, 4 * plane + 64) != hipSuccess ||
+            hipMalloc((void **)&ws.d_wdec, (uint64_t)B * n_tiles * 10 * sizeof(WDec)) != hipSuccess ||
+            hipMalloc((void **)&ws.d_dtab, (uint64_t)B * n_tiles * 10 * WD_TAB_MAX) != hipSuccess)
             return bad("hipMalloc failed (decode workspace)");
         ws.cap_tiles = (uint64_t)B * n_tiles; ws.cap_plane = plane;
     }
@@ -775,16 +785,25 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
             return bad("stream/event creation failed");
     }
     k_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, spt, pxsz, d_tiles, sel, ws.d_info, d_status);
+    // Many tiles in flight: instruction issue is the bound, so the rANS chains run 32 streams to a wave (rans2_wide_dec.hpp);
+    // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.
+    const bool wide = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * spt > 2048 || getenv("XPNG_WIDE_RANS"));
+    const uint32_t groups = (total + WD_STREAMS - 1) / WD_STREAMS;
+    if (wide) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
     // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
-        k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
+        if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<11><<<groups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
         k_dec_alpha<<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
-    k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
-    k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
+    if (wide) k_rans2_dec_chain<8><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+    else {
+        k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
+        k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
+    }
     k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");

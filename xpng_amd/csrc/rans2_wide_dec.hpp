@@ -1,0 +1,303 @@
+// "Wide" rANS v2 block decode (decompress_block_v2, libxpng.c:429-493) for large batches of tiles.
+//
+// k_rans2_decode (m1_decode.hpp) gives a whole wavefront to one stream: 2 useful lanes.  With thousands of tiles in
+// flight the machine is bound by instruction issue, so here the lanes are filled instead:
+//
+//   k_rans2_dec_prep   one wave per (tile, stream): block types 0/1/2 are finished on the spot; for rANS blocks the
+//                      frequency table is parsed and the decode tables ((F | cum << 16)[256], coarse slot -> symbol
+//                      [256]) are left in HBM together with a small descriptor
+//   k_rans2_dec_chain  one wave = the SAME stream class (context c, or alpha) of 32 tiles: lanes 2k / 2k+1 carry the
+//                      two interleaved states of tile k.  Chains of one class have similar lengths, so the wave's
+//                      trip count (its longest chain) wastes little.
+//
+// The chain loop touches global memory only at block boundaries (every 8 steps): renormalisation words are staged
+// through a 64-word LDS ring per stream, refilled by loads that are issued at one boundary and landed at the next
+// (so no s_waitcnt for global memory sits inside the 8 steps), and decoded symbols leave as one aligned 16-byte
+// store per stream and block.
+#pragma once
+#include "common.hpp"
+
+namespace xpng {
+
+struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_prep
+    uint32_t kind;     // 1 = rANS chain to run; 0 = nothing left to do
+    uint32_t pb, N, n;
+    uint32_t nw;       // renormalisation words below the two states
+    uint32_t words_off;  // byte offset of words[0] inside the tile blob
+    uint64_t out_off;  // symbol destination, relative to ctxsym (c < 9) or asym (c == 9)
+};
+
+// Decode tables of one stream: fc[256] dwords (F | cum << 16), then the coarse slot -> symbol bytes: entry g = the symbol
+// owning slot g << shift, the start of a short forward scan.  A wave runs for its slowest lane, so the scan must be
+// short for EVERY slot: buckets are 16 slots wide (2^(pb-4) entries) for pb <= 12 + (CBITS - 8); the nl-context
+// streams (pb 12) use CBITS = 8, alpha (pb 15) CBITS = 11.
+constexpr uint32_t wd_tab_bytes(uint32_t cbits) { return 1028 + (1u << cbits); }  // fc[257] (entries >= N: F = 0xFFFF, cum = 0 stop any scan) + coarse
+constexpr uint32_t WD_TAB_MAX = wd_tab_bytes(11);  // HBM stride of one stream's tables
+constexpr uint32_t WD_STREAMS = 32, WD_RING = 64;
+__host__ __device__ constexpr uint32_t wd_cbits(uint32_t c) { return c < 9 ? 8u : 11u; }
+
+// A pointer read out of a device structure is "generic" to the compiler: it would emit flat_load, which also counts on
+// lgkmcnt and so couples every LDS wait to outstanding global loads.  These go through address space 1 explicitly.
+typedef const __attribute__((address_space(1))) uint32_t *gptr32;
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const __attribute__((address_space(1))) u32x4_a4 *gptr128;
+__device__ __forceinline__ uint32_t pick32(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+__device__ __forceinline__ uint32_t gld32u(uintptr_t a) {  // unaligned-safe little-endian u32 from global memory
+    const gptr32 q = (gptr32)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3) * 8;
+    const uint32_t lo = q[0];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (q[1] << (32 - sh));
+}
+
+__global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
+                                                       TileSel sel, uint32_t spt, uint8_t *__restrict__ ctxsym,
+                                                       uint8_t *__restrict__ asym, WDec *__restrict__ wdec,
+                                                       uint8_t *__restrict__ dtab) {
+    __shared__ uint32_t fc[256];
+    __shared__ uint32_t Fs[260];
+    const uint32_t j = blockIdx.x / spt, c = blockIdx.x % spt, lane = threadIdx.x & 63;
+    WDec *wd = wdec + (uint64_t)j * 10 + c;
+    const DecTile d = info[j];
+    if (lane == 0) wd->kind = 0;
+    if (d.type == 0 || d.type == TILE_BAD) return;
+    const TileDesc t = tiles[vtile(sel, j)];
+    const uint8_t *in = d.blob + d.blk_off[c];
+    const uint64_t out_off = c < 9 ? t.pbase + d.ctx_start[c] : t.pbase;
+    uint8_t *out = (c < 9 ? ctxsym : asym) + out_off;
+    const uint32_t h0 = sgpr(ld32u(in)), type = h0 >> 24;
+    if (type == 0) return;
+    const uint32_t csz = h0 & 0xFFFFFF;
+    const uint8_t *end = in + csz;
+    const uint32_t h1 = sgpr(ld32u(in + 4)), n = h1 & 0xFFFFFF, v2 = h1 >> 24;
+    if (type == 1) {  // one distinct symbol
+        for (uint32_t i = lane; i < n; i += 64) out[i] = (uint8_t)v2;
+        return;
+    }
+    if (type == 2) {  // raw: v2 bits per symbol, MSB first
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint64_t b0 = (uint64_t)i * v2;
+            const uint8_t *wp = in + 8 + (b0 >> 5) * 4;
+            const uint32_t rel = (uint32_t)(b0 & 31);
+            const uint64_t two = ((uint64_t)ld32u(wp) << 32) | (wp + 4 < end ? ld32u(wp + 4) : 0u);
+            out[i] = (uint8_t)((two >> (64 - rel - v2)) & ((1u << v2) - 1));
+        }
+        return;
+    }
+    const uint32_t N = v2 + 2;
+    const uint32_t h2 = sgpr(ld32u(in + 8));
+    const uint32_t pb = h2 >> 24;  // 10..15, checked by k_dec_parse
+    const uint8_t *words = in + 12;
+    const uint8_t *table = in + 8 + 4ull * (h2 & 0xFFFFFF);
+    if (lane == 0) {  // frequency table: <= 256 short fields, serial bit reader
+        BitR tr{0, 0, table, end};
+        for (uint32_t i = 0; i < N; i++) {
+            uint32_t F;
+            if (type == 3) F = tr.get(pb);
+            else F = tr.get(1) ? tr.get(pb) : 0;
+            Fs[i] = F;
+        }
+    }
+    __syncthreads();
+    {   // cum by 4-per-lane partial sums + wave scan; fc[i] = F | cum << 16
+        const uint32_t b = lane * 4;
+        const uint32_t f0 = b + 0 < N ? Fs[b + 0] : 0, f1 = b + 1 < N ? Fs[b + 1] : 0, f2 = b + 2 < N ? Fs[b + 2] : 0, f3 = b + 3 < N ? Fs[b + 3] : 0;
+        const uint32_t tot = f0 + f1 + f2 + f3;
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t v = __shfl_up(incl, dd);
+            if ((int)lane >= dd) incl += v;
+        }
+        const uint32_t c0 = incl - tot, c1 = c0 + f0, c2 = c1 + f1, c3 = c2 + f2;
+        fc[b + 0] = b + 0 < N ? f0 | (c0 << 16) : 0;
+        fc[b + 1] = b + 1 < N ? f1 | (c1 << 16) : 0;
+        fc[b + 2] = b + 2 < N ? f2 | (c2 << 16) : 0;
+        fc[b + 3] = b + 3 < N ? f3 | (c3 << 16) : 0;
+    }
+    __syncthreads();
+    uint8_t *gt = dtab + ((uint64_t)j * 10 + c) * WD_TAB_MAX;
+    uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
+    for (uint32_t i = lane; i < 257; i += 64) gfc[i] = i < N ? fc[i] : 0xFFFFu;
+    {   // coarse slot -> symbol
+        const uint32_t cbits = wd_cbits(c), sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
+        for (uint32_t g0 = lane * 4; g0 < entries; g0 += 256) {
+            uint32_t pk = 0;
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t s = (g0 + q) << sh;
+                uint32_t lo = 0, hi = N - 1;  // largest index with cum <= s
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
+                }
+                while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
+                pk |= lo << (8 * q);
+            }
+            *reinterpret_cast<uint32_t *>(gt + 1028 + g0) = pk;
+        }
+    }
+    const uint8_t *sp = table - 16;  // state0 at table-16, state1 at table-8
+    if (lane == 0) {
+        WDec w;
+        w.kind = 1; w.pb = pb; w.N = N; w.n = n;
+        w.nw = (uint32_t)((sp - words) >> 2);
+        w.words_off = d.blk_off[c] + 12;
+        w.out_off = out_off;
+        *wd = w;
+    }
+}
+
+typedef __attribute__((address_space(3))) uint8_t lds8;
+typedef __attribute__((address_space(3))) uint32_t lds32;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t lds128;
+
+// Per decode step and lane (fast path, every lane active): slot -> coarse byte -> (F | cum << 16) are two dependent LDS reads; the
+// state update is one 64x32 multiply-add built from v_mad_u64_u32 + v_mad_u32_u24 (the high half of s >> pb is < 2^21,
+// F < 2^16); the pair's word cursor is an LDS address that wraps inside a 256-byte aligned ring by a bit-field insert,
+// and both candidate words come back with one ds_read2 (a mirror dword in front of the ring covers the wrap).
+template <int CBITS>
+__global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restrict__ info, uint32_t total, uint32_t c_first,
+                                                        uint32_t c_count, const WDec *__restrict__ wdec,
+                                                        const uint8_t *__restrict__ dtab, uint8_t *__restrict__ ctxsym,
+                                                        uint8_t *__restrict__ asym) {
+    constexpr uint32_t TAB = wd_tab_bytes(CBITS);
+    constexpr uint32_t TSTRIDE = TAB + 4;  // LDS stride: +1 bank per table, the lanes mostly look up the same symbol
+    __shared__ __align__(16) uint8_t ltab[WD_STREAMS * TSTRIDE];
+    __shared__ __align__(512) uint32_t ring[WD_STREAMS * 128];  // per stream: [.. 252: mirror of word 63][256..511: 64 words]
+    __shared__ __align__(32) uint8_t obuf[WD_STREAMS * 32];     // per stream: 16 symbol bytes of the block + 16 bytes nobody reads
+    const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
+    const uint32_t c = c_first + blockIdx.x % c_count, grp = blockIdx.x / c_count;
+    const uint32_t j = grp * WD_STREAMS + k;
+    bool live = j < total;
+    // decode tables of the wave's streams -> LDS
+    for (uint32_t ts = 0; ts < WD_STREAMS; ts++) {
+        const uint32_t jj = grp * WD_STREAMS + ts;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ltab + ts * TSTRIDE);
+        if (jj >= total || sgpr(wdec[(uint64_t)jj * 10 + c].kind) != 1) {
+            // no chain in this slot: its lanes idle through the loop, but their table lookups must still terminate
+            for (uint32_t i = lane; i < 257; i += 64) dst[i] = 0xFFFFu;
+            continue;
+        }
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(dtab + ((uint64_t)jj * 10 + c) * WD_TAB_MAX);
+#pragma unroll 4
+        for (uint32_t i = lane; i < TAB / 4; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const WDec *wd = wdec + (uint64_t)(live ? j : 0) * 10 + c;
+    live = live && wd->kind == 1;
+    const uintptr_t words = live ? (uintptr_t)info[j].blob + wd->words_off : 0;
+    uint8_t *out = (c < 9 ? ctxsym : asym) + (live ? wd->out_off : 0);
+    const uint32_t n = live ? wd->n : 0, pb = live ? wd->pb : 12, nw = live ? wd->nw : 0;
+    const uint32_t npairs = n >> 1, mask = (1u << pb) - 1, csh = pb > (uint32_t)CBITS ? pb - CBITS : 0;
+    const uint32_t ident = 1u << pb;  // table entry (F = 2^pb, cum = 0): the step maps s to s, which is how an idle lane waits
+    // LDS byte addresses
+    const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + 1028;
+    const uint32_t a_ring = (uint32_t)(uintptr_t)(lds32 *)ring + k * 512 + 256;  // word slot i at a_ring + 4 i
+    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + k * 32;
+    auto ring_w = [&](uint32_t idx) __attribute__((always_inline)) -> lds32 * { return (lds32 *)(uintptr_t)(a_ring + 4 * (idx & 63u)); };
+    // ---- initial ring contents: the top 64 words; the states sit right above the words
+    uint32_t rw = nw;                               // next word to pop is words[rw - 1]
+    uint32_t lo = nw > WD_RING ? nw - WD_RING : 0;  // lowest word index resident in the ring
+#pragma unroll 4
+    for (uint32_t q = 0; q < WD_RING / 2; q++) {
+        const uint32_t a = lo + 2 * q + par;
+        if (a < nw) *ring_w(a) = gld32u(words + 4ull * a);
+    }
+    *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(63);
+    uint32_t slo = 0, shi = 0x80000000u >> 0;  // state = shi:slo
+    slo = 0x80000000u; shi = 0;
+    if (live) { const uintptr_t sp = words + 4ull * nw + 8 * par; slo = gld32u(sp); shi = gld32u(sp + 4); }
+    uint32_t lof = lo;                              // lowest word index resident or in flight
+    uint32_t fa0 = 0, fhi = 0, fsh = 0;             // in-flight chunk: first word index, landing bound, byte misalignment
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    uint32_t qx = 0;
+    bool inflight = false;
+    uint32_t wp = a_ring + 4 * ((rw - 1) & 63u);    // LDS address of w1 = words[rw - 1]; w2 = words[rw - 2] sits 4 bytes below
+    uint32_t w1, w2;
+    auto fetch_w = [&]() __attribute__((always_inline)) {
+        const lds32 *p = (const lds32 *)(uintptr_t)(wp - 4);
+        w2 = p[0]; w1 = p[1];
+    };
+    fetch_w();
+    // one symbol out of this lane's state, the pair's renormalisation (state1 refills first, libxpng.c:486-487)
+    auto step = [&](bool act, uint32_t obpos) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t slot = slo & mask;
+        uint32_t sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
+        uint32_t e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym);
+        while (slot - (e >> 16) >= (e & 0xFFFFu)) { sym++; e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym); }  // entries >= N stop it (F = 0xFFFF)
+        if (!act) e = ident;
+        const uint32_t F = e & 0xFFFFu, off = slot - (e >> 16);
+        const uint32_t qlo = __builtin_amdgcn_alignbit(shi, slo, pb), qhi = shi >> pb;  // s >> pb
+        const uint64_t r0 = (uint64_t)qlo * F + off;
+        const uint32_t nlo = (uint32_t)r0, nhi = __umul24(qhi, F) + (uint32_t)(r0 >> 32);
+        const bool need = (nhi | (nlo >> 31)) == 0;  // s < 2^31
+        const uint32_t needi = need ? 1u : 0u, other = swap_pair(needi);
+        const uint32_t take = pick32(!par && other, w2, w1);
+        shi = need ? nlo : nhi;
+        slo = need ? take : nlo;
+        const uint32_t cons = needi + other;
+        wp = a_ring | ((wp - 4 * cons) & 255u);
+        fetch_w();
+        *(lds8 *)(uintptr_t)(a_ob + (act ? obpos : 16u)) = (uint8_t)sym;
+        return sym;
+    };
+    if (n & 1) {  // odd tail comes from state0 only (libxpng.c:471-476)
+        const uint32_t sym = step(par == 0, (n - 1) & 15u);
+        if (par == 0) out[n - 1] = (uint8_t)sym;
+    }
+    uint32_t T = npairs, Tmin = npairs;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t v = __shfl_xor(T, o), v2 = __shfl_xor(Tmin, o);
+        T = v > T ? v : T; Tmin = v2 < Tmin ? v2 : Tmin;
+    }
+    T = sgpr((T + 7) & ~7u); Tmin = sgpr(Tmin);
+    for (uint32_t jb = T; jb > 0;) {
+        jb -= 8;
+        const uint32_t wp0 = wp;
+        if (jb + 8 <= Tmin) {  // every lane of the wave is inside its stream
+#pragma unroll
+            for (int u = 7; u >= 0; u--) step(true, 2 * (uint32_t)u + par);
+        } else {
+#pragma unroll
+            for (int u = 7; u >= 0; u--) step(jb + (uint32_t)u < npairs, 2 * (uint32_t)u + par);
+        }
+        rw -= ((wp0 - wp) >> 2) & 63u;  // words the pair consumed in this block (<= 16)
+        // ---- block boundary: in-flight words land, symbols out, next words requested
+        // (landing first: its wait then covers only what the previous boundary issued, 8 steps ago, not this block's store)
+        if (inflight) {
+            const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, qx};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t a = fa0 + (uint32_t)i;
+                if (a < fhi) *ring_w(a) = __builtin_amdgcn_alignbyte(dw[i + 1], dw[i], fsh);
+            }
+            inflight = false;
+        }
+        *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(63);
+        if (jb < npairs && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * jb) = *(const lds128 *)(uintptr_t)a_ob;
+        lo = lof;
+        {
+            int32_t want = (int32_t)lo - 16;
+            const int32_t room = (int32_t)rw - (int32_t)WD_RING;
+            want = want > room ? want : room;
+            want = want > 0 ? want : 0;
+            if ((uint32_t)want < lo) {
+                const uint32_t a0 = (uint32_t)want + 8 * par;
+                if (a0 < lo) {
+                    const uintptr_t A = words + 4ull * a0;
+                    const gptr32 p = (gptr32)(A & ~(uintptr_t)3);
+                    const u32x4_a4 v0 = *(gptr128)p, v1 = *(gptr128)(p + 4);
+                    q0 = make_uint4(v0.x, v0.y, v0.z, v0.w); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w);
+                    qx = p[8];
+                    fa0 = a0; fhi = lo; fsh = (uint32_t)(A & 3);
+                    inflight = true;
+                }
+                lof = (uint32_t)want;
+            }
+        }
+    }
+}
+
+}  // namespace xpng

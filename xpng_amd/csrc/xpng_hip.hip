@@ -68,7 +68,7 @@ static void build_tiles(uint64_t W, uint64_t H, std::vector<TileDesc> &out, uint
             t.n = t.w * t.h;
             t.pbase = pbase; t.sbase = sbase;
             const uint64_t idx = out.size();
-            if (idx >= r0 && idx < r1) { pbase += rup(t.n + 64, 256); sbase += tile_scratch_bytes(t.n); }
+            if (idx >= r0 && idx < r1) { pbase += rup(t.n + 192, 256); sbase += tile_scratch_bytes(t.n); }
             out.push_back(t);
         }
     }
@@ -94,6 +94,12 @@ struct xpnghip_ctx {
     uint8_t **d_out_ptrs = nullptr;       // B blob (encode) / raster (decode) pointers
     std::vector<const void *> h_in_ptrs;  // what d_in_ptrs / d_out_ptrs currently hold (skip the upload when unchanged)
     std::vector<void *> h_out_ptrs;
+    // decode keeps its own pair of tables: a caller that alternates encode and decode on one context (a pipeline) would
+    // otherwise re-upload, and synchronise its stream, on every call
+    const uint8_t **d_dec_in_ptrs = nullptr;
+    uint8_t **d_dec_out_ptrs = nullptr;
+    std::vector<const void *> h_dec_in_ptrs;
+    std::vector<void *> h_dec_out_ptrs;
     WPrep *d_wprep = nullptr;   // wide entropy stage: per (tile, stream) record, encoder tables, normalised frequencies
     uint8_t *d_wtab = nullptr;
     uint16_t *d_wF = nullptr;
@@ -118,7 +124,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
-                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs,
+                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs,
                     c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     decode_ws_free(c->dec);
@@ -138,7 +144,7 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
     const uint64_t N = c->tiles.size(), VN = N * batch;
     c->r0 = r0; c->r1 = r1 < N ? r1 : N;
     const TileDesc &last = c->tiles[c->r1 - 1];
-    c->plane_img = last.pbase + rup(last.n + 64, 256);
+    c->plane_img = last.pbase + rup(last.n + 192, 256);
     c->scratch_img = last.sbase + tile_scratch_bytes(last.n);
     c->plane_stride = c->plane_img * batch;
     std::vector<TileDesc> all(VN);
@@ -175,6 +181,8 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
     ALLOC(c->d_status, 64);
     ALLOC(c->d_in_ptrs, (uint64_t)batch * 8);
     ALLOC(c->d_out_ptrs, (uint64_t)batch * 8);
+    ALLOC(c->d_dec_in_ptrs, (uint64_t)batch * 8);
+    ALLOC(c->d_dec_out_ptrs, (uint64_t)batch * 8);
 #undef ALLOC
     c->stamps = getenv("XPNG_STAMPS") != nullptr;
     if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
@@ -214,18 +222,20 @@ static int check_range(const xpnghip_ctx *c, uint64_t t0, uint64_t t1) {
 }
 
 // upload the per-image pointer tables (only when they changed: the copy comes from pageable host memory)
-static int set_ptrs(xpnghip_ctx *c, const void *const *in, void *const *outp, uint32_t nimg, hipStream_t s) {
+static int set_ptrs(xpnghip_ctx *c, const void *const *in, void *const *outp, uint32_t nimg, hipStream_t s, bool dec = false) {
     if (nimg < 1 || nimg > c->B) return fail("batch size exceeds the context's batch");
-    bool same = c->h_in_ptrs.size() == nimg && c->h_out_ptrs.size() == nimg;
-    for (uint32_t b = 0; same && b < nimg; b++) same = c->h_in_ptrs[b] == in[b] && c->h_out_ptrs[b] == outp[b];
+    std::vector<const void *> &hin = dec ? c->h_dec_in_ptrs : c->h_in_ptrs;
+    std::vector<void *> &hout = dec ? c->h_dec_out_ptrs : c->h_out_ptrs;
+    bool same = hin.size() == nimg && hout.size() == nimg;
+    for (uint32_t b = 0; same && b < nimg; b++) same = hin[b] == in[b] && hout[b] == outp[b];
     if (same) return 0;
     for (uint32_t b = 0; b < nimg; b++)
-        if (((uintptr_t)in[b] & 15) || ((uintptr_t)outp[b] & 3)) return fail("device buffers must be 16-byte aligned");
-    HIPCHK(hipMemcpyAsync(c->d_in_ptrs, in, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->d_out_ptrs, outp, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
+        if (((uintptr_t)(dec ? outp[b] : in[b]) & 15) || ((uintptr_t)(dec ? in[b] : outp[b]) & 3)) return fail("device buffers must be 16-byte aligned");
+    HIPCHK(hipMemcpyAsync(dec ? c->d_dec_in_ptrs : c->d_in_ptrs, in, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dec ? c->d_dec_out_ptrs : c->d_out_ptrs, outp, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
-    c->h_in_ptrs.assign(in, in + nimg);
-    c->h_out_ptrs.assign(outp, outp + nimg);
+    hin.assign(in, in + nimg);
+    hout.assign(outp, outp + nimg);
     return 0;
 }
 
@@ -371,7 +381,7 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     if (mode == 2 && c->pxsz != 3) return fail("mode 2 codes RGB only");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    if (set_ptrs(c, d_blobs, d_rasters, nimg, s)) return 1;
+    if (set_ptrs(c, d_blobs, d_rasters, nimg, s, true)) return 1;
     if (!blobs_len) return fail("blob lengths are required (tile headers are validated against them)");
     if (c->h_blob_len.size() != nimg || memcmp(c->h_blob_len.data(), blobs_len, (size_t)nimg * 8) != 0) {
         HIPCHK(hipMemcpyAsync(c->d_blob_len, blobs_len, (uint64_t)nimg * 8, hipMemcpyHostToDevice, s));
@@ -383,11 +393,11 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
-        return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->d_in_ptrs, c->d_blob_len, c->d_status, tile_off, (uint32_t)t0,
-                                (uint32_t)t1, c->d_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
+        return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off, (uint32_t)t0,
+                                (uint32_t)t1, c->d_dec_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
     }
-    return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_in_ptrs, c->d_blob_len, c->d_status, tile_off,
-                            (uint32_t)t0, (uint32_t)t1, c->d_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr);
+    return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off,
+                            (uint32_t)t0, (uint32_t)t1, c->d_dec_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr);
 }
 extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
                                      const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
