@@ -485,6 +485,96 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 }
 
 // --------------------------------------------------------------------------------------------------
+// The same walk for large batches: one LANE per tile, 64 tiles per wave (k_dec_walk keeps a whole wave, and 9 KB of
+// LDS, busy per tile; with thousands of tiles in flight that footprint, not the chain latency, is what hurts).
+//   head[c][lane]  = { bytes left in the current dword of queue c (next symbol lowest), position, the following dword }
+//   ringw[c][w][lane] = 64-byte window of queue c as 16 dwords, lane-minor so that 64 lanes never share a bank
+// The dependent chain of a step is ONE LDS round trip: ds_read_b128 head[cur] -> symbol -> cur.  The bookkeeping of the
+// previous step (advance the position, pull the next window dword, write the head back) is issued behind that read and
+// completes while it is in flight; when the same queue is popped twice in a row the read is stale and the registers of
+// the previous step are forwarded instead.  Queue 9 is a parking queue that returns 9 forever: a lane whose tile is
+// finished walks it.  Global memory is touched only every 16 steps: one aligned 16-byte chunk per queue is requested at
+// a boundary and lands in the window at the next one (the chunk starts are 16-byte aligned, k_dec_parse).
+__global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
+                                                      TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
+                                                      uint8_t *__restrict__ nlseq) {
+    __shared__ u32x4_t head[10 * 64];
+    __shared__ uint32_t ringw[10 * 16 * 64];
+    const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 64 + lane;
+    bool live = j < total_tiles;
+    const DecTile *d = info + (live ? j : 0);
+    live = live && d->type != 0 && d->type != TILE_BAD;
+    const TileDesc *t = tiles + vtile(sel, live ? j : 0);
+    const uint32_t total = live ? d->ctx_start[9] : 0;
+    const uintptr_t base = (uintptr_t)(ctxsym + t->pbase);
+    uint8_t *out = nlseq + t->pbase;
+    uint32_t qoff[9], have[9];
+    u32x4_t fl[9];
+    typedef const __attribute__((address_space(1))) u32x4_t *gp128;
+    const u32x4_t zero4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        qoff[c] = live ? d->ctx_start[c] : 0;
+        const gp128 src = (gp128)(base + qoff[c]);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            u32x4_t v = zero4;
+            if (live) v = src[q];
+            ringw[(c * 16 + q * 4 + 0) * 64 + lane] = v.x; ringw[(c * 16 + q * 4 + 1) * 64 + lane] = v.y;
+            ringw[(c * 16 + q * 4 + 2) * 64 + lane] = v.z; ringw[(c * 16 + q * 4 + 3) * 64 + lane] = v.w;
+            if (q == 0) { const u32x4_t h = {v.x, 0u, v.y, 0u}; head[c * 64 + lane] = h; }
+        }
+        have[c] = 3;
+        fl[c] = zero4;
+        if (live) fl[c] = src[3];  // in flight: lands at the first boundary
+    }
+#pragma unroll
+    for (int w = 0; w < 16; w++) ringw[(9 * 16 + w) * 64 + lane] = 0x09090909u;
+    { const u32x4_t h = {0x09090909u, 0u, 0x09090909u, 0u}; head[9 * 64 + lane] = h; }
+    uint32_t T = total;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(T, o); T = v > T ? v : T; }
+    T = sgpr(T);
+    uint32_t cur = total > 0 ? 0u : 9u;
+    // registers of the previous step: its queue and the head it popped from (lo, pos, nxt); queue 9 at start (harmless)
+    uint32_t pcur = 9, plo = 0x09090909u, ppos = 0, pnxt = 0x09090909u;
+    for (uint32_t kb = 0; kb < T; kb += 16) {
+        uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            // bookkeeping of the previous step: its window read goes out first, then this step's head read; both are in
+            // flight together
+            const uint32_t npos = ppos + 1;
+            const bool cross = (npos & 3u) == 0;
+            const uint32_t rr = ringw[(pcur * 16 + (((npos >> 2) + 1) & 15u)) * 64 + lane];
+            const u32x4_t r = head[cur * 64 + lane];               // (stale if cur == pcur: forwarded below)
+            const uint32_t nlo = cross ? pnxt : plo >> 8, nnxt = cross ? rr : pnxt;
+            { const u32x4_t h = {nlo, npos, nnxt, 0u}; head[pcur * 64 + lane] = h; }
+            const bool same = cur == pcur;
+            plo = same ? nlo : r.x; ppos = same ? npos : r.y; pnxt = same ? nnxt : (r.z | r.w);  // (r.w == 0; keeps the 4th register of the read alive so nothing else is loaded into it early)
+            pcur = cur;
+            const uint32_t sym = plo & 255u;
+            o[u >> 2] |= sym << (8 * (u & 3));
+            cur = kb + (uint32_t)u + 1 >= total ? 9u : (sym < 9u ? sym : 9u);  // (symbols > 8 only in corrupt streams)
+        }
+        if (kb < total) *reinterpret_cast<uint4 *>(out + kb) = make_uint4(o[0], o[1], o[2], o[3]);
+        // ---- boundary: the chunk requested 16 steps ago lands if its window slot has been read out (the window then
+        // holds >= 32 unread bytes, two blocks' worth); either way the next missing chunk is requested again.
+        // (The head of queue pcur in LDS is one pop behind the registers; a chunk index can only be underestimated by that.)
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            const uint32_t cq = head[c * 64 + lane].y >> 4;  // chunk the queue is reading from
+            if (have[c] - cq < 4) {
+                const uint32_t w0 = (c * 16 + (have[c] & 3u) * 4) * 64 + lane;
+                ringw[w0] = fl[c].x; ringw[w0 + 64] = fl[c].y; ringw[w0 + 128] = fl[c].z; ringw[w0 + 192] = fl[c].w;
+                have[c]++;
+            }
+            if (live) fl[c] = ((gp128)(base + qoff[c]))[have[c]];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // residual extraction.  Walks the tile's pixels in raster order, 1024 per step: coded flag (alpha != 0),
 // coded index = running count, bit cursor = running sum of 3*nl; pulls 3*nl bits out of k, undoes zig-zag
 // and the green subtraction, and stores one packed word per pixel: r | g<<8 | b<<16 | coded<<24.
@@ -804,7 +894,8 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
     }
-    k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
+    if (wide && !getenv("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq);
+    else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         k_dec_resid<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
