@@ -344,7 +344,8 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
 // --------------------------------------------------------------------------------------------------
 // alpha plane (RGBA).  a(x,y) = a(left) + d, except column 0: a(0,y) = a(0,y-1) + d (libxpng.c:798-800 with
 // pr = p1x_ for rows 0 / interior and p1y_ for column 0).  grid = tiles, block = 1024.
-__global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ info,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_dec_alpha(const DecTile *__restrict__ info,
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ asym, uint8_t *__restrict__ alpha) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ 
     const TileDesc t = tiles[vtile(sel, j)];
     const uint8_t *sy = asym + t.pbase;  // sy[i-1] = symbol of pixel i
     uint8_t *al = alpha + t.pbase;
-    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_wave[THREADS / 64];
     __shared__ uint32_t s_carry;
     // first pixel's alpha: 4th byte of the first k word (MSB-first R,G,B,A)
     const uint32_t a0 = ld32u(d.blob + 8) & 0xFF;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ 
     if (tid == 0) s_carry = a0;
     __syncthreads();
     if (tid == 0) al[0] = (uint8_t)a0;
-    for (uint32_t y0 = 1; y0 < t.h; y0 += 1024) {
+    for (uint32_t y0 = 1; y0 < t.h; y0 += THREADS) {
         const uint32_t y = y0 + tid;
         const uint32_t dv = y < t.h ? (uint32_t)zz_dec(sy[(uint64_t)y * t.w - 1]) & 255u : 0u;
         uint32_t incl = dv;
@@ -376,12 +377,12 @@ __global__ __launch_bounds__(1024) void k_dec_alpha(const DecTile *__restrict__ 
         for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave[w2];
         if (y < t.h) al[(uint64_t)y * t.w] = (uint8_t)(base + incl);
         __syncthreads();
-        if (tid == 1023) s_carry = (base + incl) & 255u;
+        if (tid == THREADS - 1) s_carry = (base + incl) & 255u;
         __syncthreads();
     }
     __syncthreads();
     // ---- rows: each wave scans whole rows left to right, 64 pixels per step
-    for (uint32_t y = wv; y < t.h; y += 16) {
+    for (uint32_t y = wv; y < t.h; y += THREADS / 64) {
         uint32_t carry = al[(uint64_t)y * t.w];
         for (uint32_t x0 = 1; x0 < t.w; x0 += 64) {
             const uint32_t x = x0 + lane;
@@ -578,8 +579,8 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
 // residual extraction.  Walks the tile's pixels in raster order, 1024 per step: coded flag (alpha != 0),
 // coded index = running count, bit cursor = running sum of 3*nl; pulls 3*nl bits out of k, undoes zig-zag
 // and the green subtraction, and stores one packed word per pixel: r | g<<8 | b<<16 | coded<<24.
-template <int PXSZ>
-__global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ info,
+template <int PXSZ, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict__ info,
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint8_t *__restrict__ nlseq,
                                                     uint32_t *__restrict__ resid) {
@@ -591,10 +592,11 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ 
     const uint8_t *al = alpha + t.pbase, *nls = nlseq + t.pbase;
     uint32_t *rs = resid + t.pbase;
     const int useG = d.type & 1;
-    __shared__ uint32_t s_wc[16], s_wb[16];
+    constexpr uint32_t NW = THREADS / 64;
+    __shared__ uint32_t s_wc[NW], s_wb[NW];
     uint32_t run_cnt = 0, run_bits = 8 * PXSZ;
     const uint64_t lt = lanemask_lt();
-    for (uint32_t i0 = 0; i0 < t.n; i0 += 1024) {
+    for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
         const uint32_t i = i0 + tid;
         bool coded = i < t.n && i > 0;
         if (PXSZ == 4 && coded) coded = al[i] != 0;
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ 
         if (lane == 0) s_wc[wv] = wcnt;
         __syncthreads();
         uint32_t cbase = run_cnt, ctot = 0;
-        for (uint32_t w2 = 0; w2 < 16; w2++) { const uint32_t v = s_wc[w2]; if (w2 < wv) cbase += v; ctot += v; }
+        for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t v = s_wc[w2]; if (w2 < wv) cbase += v; ctot += v; }
         const uint32_t nl = coded ? nls[cbase + rank] : 0;
         const uint32_t len = 3 * nl;
         uint32_t incl = len;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(1024) void k_dec_resid(const DecTile *__restrict__ 
         if (lane == 63) s_wb[wv] = incl;
         __syncthreads();
         uint32_t bbase = run_bits, btot = 0;
-        for (uint32_t w2 = 0; w2 < 16; w2++) { const uint32_t v = s_wb[w2]; if (w2 < wv) bbase += v; btot += v; }
+        for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t v = s_wb[w2]; if (w2 < wv) bbase += v; btot += v; }
         if (i < t.n) {
             uint32_t word = 0;
             if (coded) {
@@ -886,7 +888,8 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
         if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<11><<<groups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
-        k_dec_alpha<<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
+        if (wide) k_dec_alpha<256><<<total, 256, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
+        else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
     if (wide) k_rans2_dec_chain<8><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
@@ -898,11 +901,13 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
-        k_dec_resid<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
+        if (wide) k_dec_resid<4, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
+        else k_dec_resid<4, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
         if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
-        k_dec_resid<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
+        if (wide) k_dec_resid<3, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
+        else k_dec_resid<3, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
         if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }

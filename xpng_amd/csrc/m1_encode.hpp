@@ -338,10 +338,9 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
 //   (iii) bit cursor of k (3*nl bits per coded pixel)   -> wave inclusive scan + cross-wave offsets,
 //        bits are OR-ed MSB-first into an LDS word window and spliced into k with a carried partial word.
 // Outputs: ctx streams + their lengths, k words + count.   grid = tiles, block = 1024.
-constexpr int ST_THREADS = 1024, ST_WAVES = ST_THREADS / 64;
-constexpr int ST_WORDS = ST_THREADS * 24 / 32 + 4;
-
-template <int PXSZ>
+// THREADS = 1024 for a few tiles (shortest serial walk per tile); 256 for large batches: the chain kernels of other
+// batches in flight leave few CUs with room for a 16-wave workgroup, but almost all have room for a 4-wave one.
+template <int PXSZ, int ST_THREADS>
 __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                            const TileDesc *__restrict__ tiles, TileSel sel,
                                                            const uint8_t *__restrict__ planes, uint64_t plane_stride,
@@ -356,6 +355,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     uint8_t *sc = scratch + t.sbase;
     uint32_t *kw = reinterpret_cast<uint32_t *>(sc + off_kw(t.n));
 
+    constexpr int ST_WAVES = ST_THREADS / 64, ST_WORDS = ST_THREADS * 24 / 32 + 4;
     __shared__ uint32_t s_bits[ST_WORDS];
     __shared__ uint32_t s_run_cnt[9];
     __shared__ uint32_t s_wave_cnt[ST_WAVES][9];

@@ -288,7 +288,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
     const uint64_t bpr = c->W * PXSZ;
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
-    k_m1_streams<PXSZ><<<total, ST_THREADS, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    if ((uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     if (getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"))) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
