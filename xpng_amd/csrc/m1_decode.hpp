@@ -163,7 +163,8 @@ template <int MAXPB>
 __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__ info,
                                                      const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first,
                                                      uint32_t c_count, int only_over, uint8_t *__restrict__ ctxsym,
-                                                     uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg) {
+                                                     uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg,
+                                                     const WDec *__restrict__ wdec = nullptr) {
     __shared__ uint8_t coarse[1 << (MAXPB - 3)];  // symbol owning slot (i << 3): start of a short forward scan (8x less LDS than a
                                                     // full slot table, which is what bounds the number of resident chains per CU)
     __shared__ uint32_t fc[256];
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
     __shared__ uint32_t wring[512];
     __shared__ uint8_t oring[512];
     const uint32_t j = blockIdx.x / c_count, c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63, par = lane & 1;
+    if (only_over == 2 && wdec[(uint64_t)j * 10 + c].kind != 2) return;  // wide mode: only what k_rans2_dec_prep left to this kernel
     const DecTile d = info[j];
     if (d.type == 0 || d.type == TILE_BAD) return;
     const uint32_t vt = vtile(sel, j);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
     const uint32_t N = v2 + 2;
     const uint32_t h2 = sgpr(ld32u(in + 8));
     const int pb = (int)(h2 >> 24);
-    if ((pb > MAXPB) || (only_over && pb <= 12)) return;  // handled by the other launch
+    if ((pb > MAXPB) || (only_over == 1 && pb <= 12)) return;  // handled by the other launch
     uint64_t *stamp = dbg ? dbg + ((uint64_t)vt * 10 + c) * 8 : nullptr;
 #define XPNG_DSTAMP(k) do { if (stamp && lane == 0) stamp[k] = __builtin_readcyclecounter(); } while (0)
     XPNG_DSTAMP(0);
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
                                                       uint8_t *__restrict__ nlseq) {
     __shared__ u32x4_t head[10 * 64];
     __shared__ uint32_t ringw[10 * 16 * 64];
+    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 64 + lane;
     bool live = j < total_tiles;
     const DecTile *d = info + (live ? j : 0);
@@ -886,14 +889,17 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
-        if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<11><<<groups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<true><<<groups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
         if (wide) k_dec_alpha<256><<<total, 256, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
-    if (wide) k_rans2_dec_chain<8><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
-    else {
+    if (wide) {
+        k_rans2_dec_chain<false><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        // context streams the small layout cannot hold (PROB_BITS > 12 or more than 16 symbols: never written by the reference)
+        k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 2, ws.d_ctxsym, ws.d_asym, dbg, ws.d_wdec);
+    } else {
         k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
     }

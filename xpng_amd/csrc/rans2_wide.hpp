@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain(const TileDesc *__restrict__
                                                     uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
     __shared__ __align__(16) uint8_t ltab[WIDE_TILES * WTAB_TILE_BYTES];
+    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     const uint32_t lane = threadIdx.x & 63, lpt = 2 * spt;  // lanes per tile
     const uint32_t tsel = lane / lpt, r = lane - tsel * lpt, c = r >> 1, par = r & 1;
     const uint32_t j = blockIdx.x * WIDE_TILES + tsel;

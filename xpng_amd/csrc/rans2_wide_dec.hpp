@@ -20,21 +20,27 @@
 namespace xpng {
 
 struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_prep
-    uint32_t kind;     // 1 = rANS chain to run; 0 = nothing left to do
+    uint32_t kind;     // 0 = nothing left to do; rANS chain to run: 1 = small table layout, 2 = big
     uint32_t pb, N, n;
     uint32_t nw;       // renormalisation words below the two states
     uint32_t words_off;  // byte offset of words[0] inside the tile blob
     uint64_t out_off;  // symbol destination, relative to ctxsym (c < 9) or asym (c == 9)
 };
 
-// Decode tables of one stream: fc[256] dwords (F | cum << 16), then the coarse slot -> symbol bytes: entry g = the symbol
-// owning slot g << shift, the start of a short forward scan.  A wave runs for its slowest lane, so the scan must be
-// short for EVERY slot: buckets are 16 slots wide (2^(pb-4) entries) for pb <= 12 + (CBITS - 8); the nl-context
-// streams (pb 12) use CBITS = 8, alpha (pb 15) CBITS = 11.
-constexpr uint32_t wd_tab_bytes(uint32_t cbits) { return 1028 + (1u << cbits); }  // fc[257] (entries >= N: F = 0xFFFF, cum = 0 stop any scan) + coarse
-constexpr uint32_t WD_TAB_MAX = wd_tab_bytes(11);  // HBM stride of one stream's tables
-constexpr uint32_t WD_STREAMS = 32, WD_RING = 64;
-__host__ __device__ constexpr uint32_t wd_cbits(uint32_t c) { return c < 9 ? 8u : 11u; }
+// Decode tables of one stream: fc[FCN + 1] dwords (F | cum << 16; entries >= N hold F = 0xFFFF, cum = 0, which stops any
+// scan), then the coarse slot -> symbol bytes: entry g = the symbol owning slot g << shift, the start of a short forward
+// scan.  A wave runs for its slowest lane, so the scan must be short for EVERY slot: buckets are 16 slots wide.
+// Two layouts, chosen per stream by k_rans2_dec_prep:
+//   small (kind 1): nl-context streams as the reference writes them (pb <= 12, at most 16 symbols): 17 + 2^8 bytes/4..,
+//                   32-word ring -> 16 KB of LDS per wave, so every chain of a large batch is resident at once
+//   big   (kind 2): alpha streams (pb 15, up to 256 symbols); a context stream that does not fit `small` (never written
+//                   by the reference encoder) is left to the one-wave-per-stream kernel
+template <bool BIG> struct WdLayout {
+    static constexpr uint32_t CBITS = BIG ? 11 : 8, FCN = BIG ? 256 : 16, RING = BIG ? 64 : 32;
+    static constexpr uint32_t CO_OFF = 4 * (FCN + 1), TAB = CO_OFF + (1u << CBITS);
+};
+constexpr uint32_t WD_TAB_MAX = WdLayout<true>::TAB;  // HBM stride of one stream's tables
+constexpr uint32_t WD_STREAMS = 32;
 
 // A pointer read out of a device structure is "generic" to the compiler: it would emit flat_load, which also counts on
 // lgkmcnt and so couples every LDS wait to outstanding global loads.  These go through address space 1 explicitly.
@@ -117,10 +123,13 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
     }
     __syncthreads();
     uint8_t *gt = dtab + ((uint64_t)j * 10 + c) * WD_TAB_MAX;
+    const bool small = c < 9 && pb <= 12 && N <= WdLayout<false>::FCN;
+    const uint32_t fcn = small ? WdLayout<false>::FCN : WdLayout<true>::FCN, co_off = 4 * (fcn + 1);
+    const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayout<true>::CBITS;
     uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
-    for (uint32_t i = lane; i < 257; i += 64) gfc[i] = i < N ? fc[i] : 0xFFFFu;
+    for (uint32_t i = lane; i <= fcn; i += 64) gfc[i] = i < N ? fc[i] : 0xFFFFu;
     {   // coarse slot -> symbol
-        const uint32_t cbits = wd_cbits(c), sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
+        const uint32_t sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
         for (uint32_t g0 = lane * 4; g0 < entries; g0 += 256) {
             uint32_t pk = 0;
             for (uint32_t q = 0; q < 4; q++) {
@@ -133,13 +142,13 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
                 while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
                 pk |= lo << (8 * q);
             }
-            *reinterpret_cast<uint32_t *>(gt + 1028 + g0) = pk;
+            *reinterpret_cast<uint32_t *>(gt + co_off + g0) = pk;
         }
     }
     const uint8_t *sp = table - 16;  // state0 at table-16, state1 at table-8
     if (lane == 0) {
         WDec w;
-        w.kind = 1; w.pb = pb; w.N = N; w.n = n;
+        w.kind = small ? 1u : 2u; w.pb = pb; w.N = N; w.n = n;
         w.nw = (uint32_t)((sp - words) >> 2);
         w.words_off = d.blk_off[c] + 12;
         w.out_off = out_off;
@@ -156,15 +165,19 @@ typedef __attribute__((address_space(3))) u32x4_t lds128;
 // state update is one 64x32 multiply-add built from v_mad_u64_u32 + v_mad_u32_u24 (the high half of s >> pb is < 2^21,
 // F < 2^16); the pair's word cursor is an LDS address that wraps inside a 256-byte aligned ring by a bit-field insert,
 // and both candidate words come back with one ds_read2 (a mirror dword in front of the ring covers the wrap).
-template <int CBITS>
+template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restrict__ info, uint32_t total, uint32_t c_first,
                                                         uint32_t c_count, const WDec *__restrict__ wdec,
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ ctxsym,
                                                         uint8_t *__restrict__ asym) {
-    constexpr uint32_t TAB = wd_tab_bytes(CBITS);
+    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    typedef WdLayout<BIG> L;
+    constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, WD_RING = L::RING, KIND = BIG ? 2 : 1;
     constexpr uint32_t TSTRIDE = TAB + 4;  // LDS stride: +1 bank per table, the lanes mostly look up the same symbol
+    constexpr uint32_t PER = WD_RING / 8;      // words one lane requests per boundary (the pair: a quarter of the ring)
+    constexpr uint32_t RSTRIDE = 4 * WD_RING + 4;  // per stream: [mirror of the last ring word][WD_RING words]
     __shared__ __align__(16) uint8_t ltab[WD_STREAMS * TSTRIDE];
-    __shared__ __align__(512) uint32_t ring[WD_STREAMS * 128];  // per stream: [.. 252: mirror of word 63][256..511: 64 words]
+    __shared__ __align__(16) uint8_t ring[WD_STREAMS * RSTRIDE];
     __shared__ __align__(32) uint8_t obuf[WD_STREAMS * 32];     // per stream: 16 symbol bytes of the block + 16 bytes nobody reads
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t c = c_first + blockIdx.x % c_count, grp = blockIdx.x / c_count;
@@ -174,9 +187,9 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     for (uint32_t ts = 0; ts < WD_STREAMS; ts++) {
         const uint32_t jj = grp * WD_STREAMS + ts;
         uint32_t *dst = reinterpret_cast<uint32_t *>(ltab + ts * TSTRIDE);
-        if (jj >= total || sgpr(wdec[(uint64_t)jj * 10 + c].kind) != 1) {
+        if (jj >= total || sgpr(wdec[(uint64_t)jj * 10 + c].kind) != KIND) {
             // no chain in this slot: its lanes idle through the loop, but their table lookups must still terminate
-            for (uint32_t i = lane; i < 257; i += 64) dst[i] = 0xFFFFu;
+            for (uint32_t i = lane; i < TAB / 4; i += 64) dst[i] = i <= L::FCN ? 0xFFFFu : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
             continue;
         }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dtab + ((uint64_t)jj * 10 + c) * WD_TAB_MAX);
@@ -185,17 +198,17 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     }
     __syncthreads();
     const WDec *wd = wdec + (uint64_t)(live ? j : 0) * 10 + c;
-    live = live && wd->kind == 1;
+    live = live && wd->kind == KIND;
     const uintptr_t words = live ? (uintptr_t)info[j].blob + wd->words_off : 0;
     uint8_t *out = (c < 9 ? ctxsym : asym) + (live ? wd->out_off : 0);
     const uint32_t n = live ? wd->n : 0, pb = live ? wd->pb : 12, nw = live ? wd->nw : 0;
     const uint32_t npairs = n >> 1, mask = (1u << pb) - 1, csh = pb > (uint32_t)CBITS ? pb - CBITS : 0;
     const uint32_t ident = 1u << pb;  // table entry (F = 2^pb, cum = 0): the step maps s to s, which is how an idle lane waits
     // LDS byte addresses
-    const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + 1028;
-    const uint32_t a_ring = (uint32_t)(uintptr_t)(lds32 *)ring + k * 512 + 256;  // word slot i at a_ring + 4 i
+    const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + L::CO_OFF;
+    const uint32_t a_ring = (uint32_t)(uintptr_t)(lds8 *)ring + k * RSTRIDE + 4;  // word slot i at a_ring + 4 i, the mirror at a_ring - 4
     const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + k * 32;
-    auto ring_w = [&](uint32_t idx) __attribute__((always_inline)) -> lds32 * { return (lds32 *)(uintptr_t)(a_ring + 4 * (idx & 63u)); };
+    auto ring_w = [&](uint32_t idx) __attribute__((always_inline)) -> lds32 * { return (lds32 *)(uintptr_t)(a_ring + 4 * (idx & (WD_RING - 1))); };
     // ---- initial ring contents: the top 64 words; the states sit right above the words
     uint32_t rw = nw;                               // next word to pop is words[rw - 1]
     uint32_t lo = nw > WD_RING ? nw - WD_RING : 0;  // lowest word index resident in the ring
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         const uint32_t a = lo + 2 * q + par;
         if (a < nw) *ring_w(a) = gld32u(words + 4ull * a);
     }
-    *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(63);
+    *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(WD_RING - 1);
     uint32_t slo = 0, shi = 0x80000000u >> 0;  // state = shi:slo
     slo = 0x80000000u; shi = 0;
     if (live) { const uintptr_t sp = words + 4ull * nw + 8 * par; slo = gld32u(sp); shi = gld32u(sp + 4); }
@@ -213,10 +226,10 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     uint32_t qx = 0;
     bool inflight = false;
-    uint32_t wp = a_ring + 4 * ((rw - 1) & 63u);    // LDS address of w1 = words[rw - 1]; w2 = words[rw - 2] sits 4 bytes below
+    uint32_t wi = (rw - 1) & (WD_RING - 1);         // ring slot of w1 = words[rw - 1]; w2 = words[rw - 2] sits 4 bytes below (mirror for slot 0)
     uint32_t w1, w2;
     auto fetch_w = [&]() __attribute__((always_inline)) {
-        const lds32 *p = (const lds32 *)(uintptr_t)(wp - 4);
+        const lds32 *p = (const lds32 *)(uintptr_t)(a_ring - 4 + 4 * wi);
         w2 = p[0]; w1 = p[1];
     };
     fetch_w();
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         shi = need ? nlo : nhi;
         slo = need ? take : nlo;
         const uint32_t cons = needi + other;
-        wp = a_ring | ((wp - 4 * cons) & 255u);
+        wi = (wi - cons) & (WD_RING - 1);
         fetch_w();
         *(lds8 *)(uintptr_t)(a_ob + (act ? obpos : 16u)) = (uint8_t)sym;
         return sym;
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     T = sgpr((T + 7) & ~7u); Tmin = sgpr(Tmin);
     for (uint32_t jb = T; jb > 0;) {
         jb -= 8;
-        const uint32_t wp0 = wp;
+        const uint32_t wi0 = wi;
         if (jb + 8 <= Tmin) {  // every lane of the wave is inside its stream
 #pragma unroll
             for (int u = 7; u >= 0; u--) step(true, 2 * (uint32_t)u + par);
@@ -263,34 +276,35 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
 #pragma unroll
             for (int u = 7; u >= 0; u--) step(jb + (uint32_t)u < npairs, 2 * (uint32_t)u + par);
         }
-        rw -= ((wp0 - wp) >> 2) & 63u;  // words the pair consumed in this block (<= 16)
+        rw -= (wi0 - wi) & (WD_RING - 1);  // words the pair consumed in this block (at most two per step)
         // ---- block boundary: in-flight words land, symbols out, next words requested
         // (landing first: its wait then covers only what the previous boundary issued, 8 steps ago, not this block's store)
         if (inflight) {
-            const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, qx};
+            const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, PER > 4 ? q1.x : qx, q1.y, q1.z, q1.w, qx};
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < (int)PER; i++) {
                 const uint32_t a = fa0 + (uint32_t)i;
                 if (a < fhi) *ring_w(a) = __builtin_amdgcn_alignbyte(dw[i + 1], dw[i], fsh);
             }
             inflight = false;
         }
-        *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(63);
+        *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(WD_RING - 1);
         if (jb < npairs && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * jb) = *(const lds128 *)(uintptr_t)a_ob;
         lo = lof;
         {
-            int32_t want = (int32_t)lo - 16;
+            int32_t want = (int32_t)lo - (int32_t)(2 * PER);
             const int32_t room = (int32_t)rw - (int32_t)WD_RING;
             want = want > room ? want : room;
             want = want > 0 ? want : 0;
             if ((uint32_t)want < lo) {
-                const uint32_t a0 = (uint32_t)want + 8 * par;
+                const uint32_t a0 = (uint32_t)want + PER * par;
                 if (a0 < lo) {
                     const uintptr_t A = words + 4ull * a0;
                     const gptr32 p = (gptr32)(A & ~(uintptr_t)3);
-                    const u32x4_a4 v0 = *(gptr128)p, v1 = *(gptr128)(p + 4);
-                    q0 = make_uint4(v0.x, v0.y, v0.z, v0.w); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w);
-                    qx = p[8];
+                    const u32x4_a4 v0 = *(gptr128)p;
+                    q0 = make_uint4(v0.x, v0.y, v0.z, v0.w);
+                    if (PER > 4) { const u32x4_a4 v1 = *(gptr128)(p + 4); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w); }
+                    qx = p[PER];
                     fa0 = a0; fhi = lo; fsh = (uint32_t)(A & 3);
                     inflight = true;
                 }
