@@ -179,7 +179,7 @@ __device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, 
     return z;
 }
 
-constexpr uint32_t TR_ROWS = 16, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
+constexpr uint32_t TR_ROWS = 8, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
 // phase 2 of k_m1_transform_rgba, specialised on the tile's predictor flags so that no per-pixel branch on them remains
 template <int useGrad, int useG>
 __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first,
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
         const uint32_t chunks = (uint32_t)(((g0 & 15) + row_bytes + 15) >> 4) + ((bpr & 15) ? 1 : 0);  // per row, upper bound
         // All of a thread's loads are issued before the first LDS store: ~8 x 16 B in flight per thread (Little's law:
         // 6 TB/s x ~2 us of loaded latency needs ~50 KB in flight per CU).
-        constexpr int LD = 12;  // (TR_ROWS + 1) * (TR_MAXW * 4 / 16 + 1) / 256 rounded up
+        constexpr int LD = ((TR_ROWS + 1) * (TR_MAXW * 4 / 16 + 2) + 255) / 256;  // chunks per thread, upper bound
         const uint32_t total_chunks = lrows * chunks;
         const float inv_chunks = 1.0f / (float)chunks;
         uint4 v[LD];

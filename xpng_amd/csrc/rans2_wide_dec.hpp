@@ -36,7 +36,7 @@ struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_p
 //   big   (kind 2): alpha streams (pb 15, up to 256 symbols); a context stream that does not fit `small` (never written
 //                   by the reference encoder) is left to the one-wave-per-stream kernel
 template <bool BIG> struct WdLayout {
-    static constexpr uint32_t CBITS = BIG ? 11 : 8, FCN = BIG ? 256 : 16, RING = BIG ? 64 : 32;
+    static constexpr uint32_t CBITS = BIG ? 10 : 8, FCN = BIG ? 256 : 16, RING = BIG ? 64 : 32;
     static constexpr uint32_t CO_OFF = 4 * (FCN + 1), TAB = CO_OFF + (1u << CBITS);
 };
 constexpr uint32_t WD_TAB_MAX = WdLayout<true>::TAB;  // HBM stride of one stream's tables
