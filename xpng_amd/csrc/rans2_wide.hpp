@@ -142,6 +142,121 @@ __global__ __launch_bounds__(64) void k_rans2_chain(const TileDesc *__restrict__
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
 }
 
+// Block-synchronous form of the chain, packed by stream class (BIG: the alpha streams of 16 tiles, 32 lanes; else
+// context stream c of 32 tiles, 64 lanes), so that the chains of one wave have similar lengths and a wave holds only the
+// tables of its own class in LDS (8 KB for a context class).  Inside a block of 8 steps nothing touches global memory:
+//   * the 8 symbols a lane codes in a block arrive as one aligned 16-byte load (+1 dword for the alpha plane, whose
+//     symbols start at byte 1) issued one block earlier, and are picked out of registers (v_perm / v_bfe);
+//   * renormalisation words are staged in LDS in emission order (state0's word first) and leave at the block boundary as
+//     16-byte stores.  Words past the pair's count are scratch: the next block, or k_rans2_finish, overwrites them.
+// So no s_waitcnt for a global access sits in the dependent chain (a conditional store per step does exactly that on
+// gfx9, where stores count on vmcnt).
+template <bool BIG>
+__global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
+                                                     const uint8_t *__restrict__ planes, uint64_t plane_stride,
+                                                     uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
+                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
+    constexpr uint32_t TPW = BIG ? 16 : 32;       // tiles (streams) per wave
+    constexpr uint32_t TAB = BIG ? 4096 : 256;    // bytes of one encoder table
+    constexpr uint32_t TSTRIDE = TAB + 16;        // +4 banks per table: lanes mostly look up the same symbol
+    constexpr uint32_t SH = BIG ? 1 : 0;          // byte phase of the symbols inside 16-byte chunks (alpha symbol of pixel i is plane byte i)
+    constexpr int PB = BIG ? 15 : 12;
+    __shared__ __align__(16) uint8_t ltab[TPW * TSTRIDE];
+    __shared__ __align__(16) uint32_t wbuf[TPW * 32];  // per stream: 16 staged words + 16 nobody reads
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
+    const uint32_t c = BIG ? 9 : blockIdx.x % 9, grp = BIG ? blockIdx.x : blockIdx.x / 9;
+    const uint32_t j = grp * TPW + k;
+    bool live = k < TPW && j < total;
+    for (uint32_t ts = 0; ts < TPW; ts++) {
+        const uint32_t jj = grp * TPW + ts;
+        if (jj >= total) break;
+        const uint4 *src = reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES + wtab_off(c));
+        uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * TSTRIDE);
+        for (uint32_t i = lane; i < TAB / 16; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t tile = vtile(sel, live ? j : 0);
+    const TileDesc *t = tiles + tile;
+    uint8_t *sc = scratch + t->sbase;
+    WPrep *p = prep + (uint64_t)tile * 10 + c;
+    live = live && p->kind == 1;
+    const uint8_t *in = BIG ? planes + 4 * plane_stride + t->pbase : sc + off_ctx(t->n, (int)c);  // 16-byte aligned; symbol i at in[i + SH]
+    const uint32_t n = !live ? 0 : BIG ? t->n - 1 : ctx_n[(uint64_t)tile * 9 + c];
+    const uint32_t mysteps = (n + 1 - par) >> 1;  // state0 codes ceil(n/2) symbols, state1 floor(n/2)
+    uint32_t T = mysteps;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(T, o); T = v > T ? v : T; }
+    T = sgpr((T + 7) & ~7u);
+    const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
+    uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t->n, (int)c)) + 3;
+    uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
+    // symbols of block b (pair symbols 16b .. 16b+15) = bytes [16b + SH, 16b + SH + 16) of `in`
+    uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;  // in flight: the block after the current one
+    auto request = [&](uint32_t b) __attribute__((always_inline)) {
+        if (8 * b < mysteps) {
+            const uint8_t *a = in + 16ull * b;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a);
+            f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
+            if (SH) f4 = *reinterpret_cast<const uint32_t *>(a + 16);
+        }
+    };
+    uint32_t sy0 = 0, sy1 = 0;  // this lane's 8 symbols of the current block, one per byte
+    auto land = [&]() __attribute__((always_inline)) {
+        uint32_t d0 = f0, d1 = f1, d2 = f2, d3 = f3;
+        if (SH) {
+            d0 = __builtin_amdgcn_alignbyte(f1, f0, SH); d1 = __builtin_amdgcn_alignbyte(f2, f1, SH);
+            d2 = __builtin_amdgcn_alignbyte(f3, f2, SH); d3 = __builtin_amdgcn_alignbyte(f4, f3, SH);
+        }
+        const uint32_t selb = par ? 0x07050301u : 0x06040200u;  // odd / even bytes of a dword pair
+        sy0 = __builtin_amdgcn_perm(d1, d0, selb);
+        sy1 = __builtin_amdgcn_perm(d3, d2, selb);
+    };
+    request(0); land(); request(1);
+    constexpr uint32_t cmpl_base = 1u << PB;
+    constexpr int thr_shift = 31 - PB;
+    uint64_t s = RANS_L;
+    uint32_t cnt = 0;
+    EncSym e = tab[sy0 & 255u];
+    for (uint32_t kb = 0; kb < T; kb += 8) {
+        uint32_t cb = 0;  // words the pair has staged in this block
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            // table entry of the NEXT step (its LDS latency hides under this step's arithmetic); the first symbol of the next
+            // block is not in registers yet, that entry is read after the boundary
+            EncSym en = e;
+            if (u < 7) en = tab[((u + 1 < 4 ? sy0 : sy1) >> (8 * ((u + 1) & 3))) & 255u];
+            const bool act = kb + (uint32_t)u < mysteps;
+            const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
+            const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
+            const uint32_t other = swap_pair(emit);
+            wb[emit ? cb + (par ? other : 0u) : 16u + par] = (uint32_t)s;  // state0's word first (libxpng.c:370-373)
+            if (emit) s >>= 32;
+            cb += emit + other;
+            if (act) {
+                const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
+                const uint64_t q = __umul64hi(s, rcp) >> rsh;
+                s += e.bias + q * (uint64_t)(cmpl_base - freq);
+            }
+            e = en;
+        }
+        // ---- boundary: staged words out (lane `par` stores words 8 par .. 8 par + 7), next block's symbols land
+        if (cb > 8 * par) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(wb + 8 * par);
+            typedef uint32_t u32x4_a4w __attribute__((ext_vector_type(4), aligned(4)));
+            u32x4_a4w *dst = reinterpret_cast<u32x4_a4w *>(w + cnt + 8 * par);
+            const uint4 a = src[0];
+            dst[0] = u32x4_a4w{a.x, a.y, a.z, a.w};
+            if (cb > 8 * par + 4) { const uint4 b2 = src[1]; dst[1] = u32x4_a4w{b2.x, b2.y, b2.z, b2.w}; }
+        }
+        cnt += cb;
+        land();
+        request((kb >> 3) + 2);
+        e = tab[sy0 & 255u];
+    }
+    if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
+}
+
 __global__ __launch_bounds__(64) void k_rans2_finish(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,

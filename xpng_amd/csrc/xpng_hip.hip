@@ -96,6 +96,8 @@ struct xpnghip_ctx {
     std::vector<void *> h_out_ptrs;
     // decode keeps its own pair of tables: a caller that alternates encode and decode on one context (a pipeline) would
     // otherwise re-upload, and synchronise its stream, on every call
+    hipStream_t enc_side = nullptr;       // the alpha chains of a batched encode run beside the context chains
+    hipEvent_t ev_enc_fork = nullptr, ev_enc_join = nullptr;
     const uint8_t **d_dec_in_ptrs = nullptr;
     uint8_t **d_dec_out_ptrs = nullptr;
     std::vector<const void *> h_dec_in_ptrs;
@@ -127,6 +129,9 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs,
                     c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
+    if (c->ev_enc_fork) (void)hipEventDestroy(c->ev_enc_fork);
+    if (c->ev_enc_join) (void)hipEventDestroy(c->ev_enc_join);
     decode_ws_free(c->dec);
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -295,7 +300,23 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
         k_rans2_prep<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        k_rans2_chain<<<(total + WIDE_TILES - 1) / WIDE_TILES, 64, 0, s>>>(c->d_tiles, sel, total, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        if (getenv("XPNG_MIXED_CHAIN")) k_rans2_chain<<<(total + WIDE_TILES - 1) / WIDE_TILES, 64, 0, s>>>(c->d_tiles, sel, total, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        else {
+            // the alpha chains are the longest: they run on their own stream beside the context chains
+            if (PXSZ == 4) {
+                if (!c->enc_side) {
+                    HIPCHK(hipStreamCreateWithFlags(&c->enc_side, hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
+                }
+                HIPCHK(hipEventRecord(c->ev_enc_fork, s));
+                HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
+                k_rans2_chain2<true><<<(total + 15) / 16, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+                HIPCHK(hipEventRecord(c->ev_enc_join, c->enc_side));
+            }
+            k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+            if (PXSZ == 4) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
+        }
         k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
