@@ -281,3 +281,69 @@ def test_corrupt_files_are_rejected_not_executed(gpu, po, tmp_path):
         assert rejected >= 8
         p.write_bytes(good)
         assert np.array_equal(gpu.load(str(p)), raster)
+
+
+def test_batch_kernels_forced_on_small_inputs(gpu, manifest, po, tmp_path, monkeypatch):
+    """Large batches switch the entropy stage to its "wide" kernels (many streams per wavefront: rans2_wide.hpp,
+    rans2_wide_dec.hpp, k_dec_walk_wide) and to 256-thread workgroups.  XPNG_WIDE_RANS=1 forces that path for any input, so
+    the goldens, the edge cases and the corrupt-file behaviour are checked on it too."""
+    monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    checked = 0
+    for name, ent in small_entries(manifest):
+        g = ent.get("L1")
+        if g is None:
+            continue
+        raster = golden_raster(name, ent)
+        out = tmp_path / "o.xpng"
+        gpu.store(1, raster, str(out))
+        data = out.read_bytes()
+        assert len(data) == g["size"] and md5(data) == g["md5"], name
+        back = gpu.load(str(out))
+        want = np.ascontiguousarray(po.normalize_rgba(raster))  # (what the file holds: hidden colours zeroed, opaque alpha dropped)
+        assert back.shape == want.shape and np.array_equal(back, want), name
+        checked += 1
+    assert checked >= 100
+    from xpng_amd.synth import synth_raster
+    rng = np.random.default_rng(11)
+    raster = synth_raster("photo", 700, 500, True)
+    good = po.encode_image(1, raster)
+    p = tmp_path / "x.xpng"
+    for trial in range(12):
+        bad = bytearray(good)
+        for _ in range(8):
+            o = int(rng.integers(8, len(bad) - 4))
+            bad[o:o + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+        p.write_bytes(bytes(bad))
+        try:
+            assert gpu.load(str(p)).shape == raster.shape
+        except gpu.XpngError:
+            pass
+    p.write_bytes(good)
+    assert np.array_equal(gpu.load(str(p)), raster)
+
+
+def test_large_batch_takes_the_wide_path_and_matches(gpu, po):
+    """A batch big enough to select the wide kernels by itself (tiles x streams > 2048)."""
+    import torch
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import synth_raster
+    W, H, B = 1800, 1500, 18   # 12 tiles x 10 streams x 18 images = 2160 chains
+    base = [synth_raster(k, W, H, True, seed=s + 1) for s, k in enumerate(("photo", "noise", "photo"))]
+    ctx = gpu.Context(W, H, 4, batch=B)
+    assert ctx.n_tiles * 10 * B > 2048
+    d_r = [torch.from_numpy(base[i % 3]).cuda() for i in range(B)]
+    d_b = [torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    lens = ctx.encode_device_batch(1, [t.data_ptr() for t in d_r], [t.data_ptr() for t in d_b])
+    want = [po.encode_tiles(1, r) for r in base]
+    offs = []
+    for i in range(B):
+        blob = d_b[i][:lens[i]].cpu().numpy().tobytes()
+        assert blob == want[i % 3], i
+        offs.append(walk_tile_offsets(blob, ctx.n_tiles)[0])
+    d_o = [torch.zeros(W * H * 4 + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    ctx.decode_device_batch(1, [t.data_ptr() for t in d_b], lens, offs, [t.data_ptr() for t in d_o])
+    torch.cuda.synchronize()
+    assert ctx.decode_status() == 0
+    for i in range(B):
+        assert np.array_equal(d_o[i][: W * H * 4].cpu().numpy().reshape(H, W, 4), base[i % 3]), i
+    ctx.close()

@@ -883,20 +883,21 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // Many tiles in flight: instruction issue is the bound, so the rANS chains run 32 streams to a wave (rans2_wide_dec.hpp);
     // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.
     const bool wide = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * spt > 2048 || getenv("XPNG_WIDE_RANS"));
-    const uint32_t groups = (total + WD_STREAMS - 1) / WD_STREAMS;
+    constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 8;
+    const uint32_t groups = (total + WD_CTX_STREAMS - 1) / WD_CTX_STREAMS, agroups = (total + WD_ALPHA_STREAMS - 1) / WD_ALPHA_STREAMS;
     if (wide) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
     // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
-        if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<true><<<groups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
         if (wide) k_dec_alpha<256><<<total, 256, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
     if (wide) {
-        k_rans2_dec_chain<false><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        k_rans2_dec_chain<false, WD_CTX_STREAMS, false><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         // context streams the small layout cannot hold (PROB_BITS > 12 or more than 16 symbols: never written by the reference)
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 2, ws.d_ctxsym, ws.d_asym, dbg, ws.d_wdec);
     } else {

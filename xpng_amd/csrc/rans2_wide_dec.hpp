@@ -25,6 +25,7 @@ struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_p
     uint32_t nw;       // renormalisation words below the two states
     uint32_t words_off;  // byte offset of words[0] inside the tile blob
     uint64_t out_off;  // symbol destination, relative to ctxsym (c < 9) or asym (c == 9)
+    uint32_t hot0, hot1;  // the two most probable symbols
 };
 
 // Decode tables of one stream: fc[FCN + 1] dwords (F | cum << 16; entries >= N hold F = 0xFFFF, cum = 0, which stops any
@@ -40,7 +41,6 @@ template <bool BIG> struct WdLayout {
     static constexpr uint32_t CO_OFF = 4 * (FCN + 1), TAB = CO_OFF + (1u << CBITS);
 };
 constexpr uint32_t WD_TAB_MAX = WdLayout<true>::TAB;  // HBM stride of one stream's tables
-constexpr uint32_t WD_STREAMS = 32;
 
 // A pointer read out of a device structure is "generic" to the compiler: it would emit flat_load, which also counts on
 // lgkmcnt and so couples every LDS wait to outstanding global loads.  These go through address space 1 explicitly.
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
         }
     }
     __syncthreads();
+    uint32_t hot0, hot1;  // (F << 8 | sym) of the two most probable symbols
     {   // cum by 4-per-lane partial sums + wave scan; fc[i] = F | cum << 16
         const uint32_t b = lane * 4;
         const uint32_t f0 = b + 0 < N ? Fs[b + 0] : 0, f1 = b + 1 < N ? Fs[b + 1] : 0, f2 = b + 2 < N ? Fs[b + 2] : 0, f3 = b + 3 < N ? Fs[b + 3] : 0;
@@ -120,6 +121,18 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
         fc[b + 1] = b + 1 < N ? f1 | (c1 << 16) : 0;
         fc[b + 2] = b + 2 < N ? f2 | (c2 << 16) : 0;
         fc[b + 3] = b + 3 < N ? f3 | (c3 << 16) : 0;
+        auto wmax = [&](uint32_t v) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(v, off); v = o > v ? o : v; }
+            return v;
+        };
+        const uint32_t k0 = (f0 << 8) | (b + 0), k1 = (f1 << 8) | (b + 1), k2 = (f2 << 8) | (b + 2), k3 = (f3 << 8) | (b + 3);
+        uint32_t m = k0 > k1 ? k0 : k1; m = k2 > m ? k2 : m; m = k3 > m ? k3 : m;
+        hot0 = wmax(m);
+        auto ex = [&](uint32_t k) { return k == hot0 ? 0u : k; };
+        uint32_t m2 = ex(k0) > ex(k1) ? ex(k0) : ex(k1); m2 = ex(k2) > m2 ? ex(k2) : m2; m2 = ex(k3) > m2 ? ex(k3) : m2;
+        hot1 = wmax(m2);
+        if ((hot1 >> 8) == 0) hot1 = hot0;  // (a single used symbol cannot happen in a type-3/4 block; keep the entry valid anyway)
     }
     __syncthreads();
     uint8_t *gt = dtab + ((uint64_t)j * 10 + c) * WD_TAB_MAX;
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
         w.nw = (uint32_t)((sp - words) >> 2);
         w.words_off = d.blk_off[c] + 12;
         w.out_off = out_off;
+        w.hot0 = hot0 & 255u; w.hot1 = hot1 & 255u;
         *wd = w;
     }
 }
@@ -165,7 +179,11 @@ typedef __attribute__((address_space(3))) u32x4_t lds128;
 // state update is one 64x32 multiply-add built from v_mad_u64_u32 + v_mad_u32_u24 (the high half of s >> pb is < 2^21,
 // F < 2^16); the pair's word cursor is an LDS address that wraps inside a 256-byte aligned ring by a bit-field insert,
 // and both candidate words come back with one ds_read2 (a mirror dword in front of the ring covers the wrap).
-template <bool BIG>
+// STREAMS per wave (2 lanes each; further lanes idle).  HOT: the (F, cum) of the two most probable symbols live in registers
+// and a step in which EVERY lane of the wave lands in one of them skips both table reads (which is most steps when the
+// streams are skewed and the wave carries few of them: alpha runs 8 streams per wave for that reason, trading lanes for
+// latency on the longest chain of the decode).
+template <bool BIG, int STREAMS, bool HOT>
 __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restrict__ info, uint32_t total, uint32_t c_first,
                                                         uint32_t c_count, const WDec *__restrict__ wdec,
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ ctxsym,
@@ -176,13 +194,14 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     constexpr uint32_t TSTRIDE = TAB + 4;  // LDS stride: +1 bank per table, the lanes mostly look up the same symbol
     constexpr uint32_t PER = WD_RING / 8;      // words one lane requests per boundary (the pair: a quarter of the ring)
     constexpr uint32_t RSTRIDE = 4 * WD_RING + 4;  // per stream: [mirror of the last ring word][WD_RING words]
+    constexpr uint32_t WD_STREAMS = STREAMS;
     __shared__ __align__(16) uint8_t ltab[WD_STREAMS * TSTRIDE];
     __shared__ __align__(16) uint8_t ring[WD_STREAMS * RSTRIDE];
     __shared__ __align__(32) uint8_t obuf[WD_STREAMS * 32];     // per stream: 16 symbol bytes of the block + 16 bytes nobody reads
-    const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
+    const uint32_t lane = threadIdx.x & 63, kraw = lane >> 1, k = kraw < WD_STREAMS ? kraw : 0, par = lane & 1;  // (idle lanes alias stream 0's LDS harmlessly)
     const uint32_t c = c_first + blockIdx.x % c_count, grp = blockIdx.x / c_count;
-    const uint32_t j = grp * WD_STREAMS + k;
-    bool live = j < total;
+    const uint32_t j = grp * WD_STREAMS + kraw;
+    bool live = kraw < WD_STREAMS && j < total;
     // decode tables of the wave's streams -> LDS
     for (uint32_t ts = 0; ts < WD_STREAMS; ts++) {
         const uint32_t jj = grp * WD_STREAMS + ts;
@@ -233,14 +252,27 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         w2 = p[0]; w1 = p[1];
     };
     fetch_w();
+    uint32_t hs0 = 0, hs1 = 0, hC0 = 0, hF0 = 0x10000u, hC1 = 0, hF1 = 0;  // idle lanes: "always hit" (their step is the identity anyway)
+    if (HOT && live) {
+        hs0 = wd->hot0; hs1 = wd->hot1;
+        const uint32_t e0 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs0), e1 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs1);
+        hF0 = e0 & 0xFFFFu; hC0 = e0 >> 16; hF1 = e1 & 0xFFFFu; hC1 = e1 >> 16;
+    }
     // one symbol out of this lane's state, the pair's renormalisation (state1 refills first, libxpng.c:486-487)
     auto step = [&](bool act, uint32_t obpos) __attribute__((always_inline)) -> uint32_t {
         const uint32_t slot = slo & mask;
-        uint32_t sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
-        uint32_t e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym);
-        while (slot - (e >> 16) >= (e & 0xFFFFu)) { sym++; e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym); }  // entries >= N stop it (F = 0xFFFF)
-        if (!act) e = ident;
-        const uint32_t F = e & 0xFFFFu, off = slot - (e >> 16);
+        uint32_t sym, F, off;
+        const uint32_t d0 = slot - hC0, d1 = slot - hC1;
+        const bool h0 = d0 < hF0, h1 = d1 < hF1;
+        if (HOT && __ballot(!(h0 || h1)) == 0) {
+            sym = h0 ? hs0 : hs1; F = h0 ? hF0 : hF1; off = h0 ? d0 : d1;
+        } else {
+            sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
+            uint32_t e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym);
+            while (slot - (e >> 16) >= (e & 0xFFFFu)) { sym++; e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym); }  // entries >= N stop it (F = 0xFFFF)
+            F = e & 0xFFFFu; off = slot - (e >> 16);
+        }
+        if (!act) { F = ident; off = slot; }
         const uint32_t qlo = __builtin_amdgcn_alignbit(shi, slo, pb), qhi = shi >> pb;  // s >> pb
         const uint64_t r0 = (uint64_t)qlo * F + off;
         const uint32_t nlo = (uint32_t)r0, nhi = __umul24(qhi, F) + (uint32_t)(r0 >> 32);
