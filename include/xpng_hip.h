@@ -40,6 +40,29 @@ int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w, uint64_t h
 int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
                          int pxsz, uint8_t *raster);
 
+/* ---- staged image: upload once, normalise and test on the device ------------------------------------
+ *
+ * xpng_store's pre-passes over the whole raster, moved off the host:
+ *   xpnghip_image_begin          <->  normalize_RGBA, libxpng.c:688-721 (called at libxpng.c:733).  Uploads the caller's
+ *                                     raster (w*h*pxsz_in bytes, host memory) and, for RGBA, applies the rule on the device:
+ *                                     hidden colours under alpha 0 -> those pixels zeroed; no translucent pixel -> repacked
+ *                                     to RGB.  *pxsz_out = 3 or 4 = bytes per pixel of the staged (normalised) raster.
+ *   xpnghip_image_single_colour  <->  the whole-image test of libxpng.c:741-753: *single = 1 if every pixel equals the first.
+ *   xpnghip_image_encode         <->  libxpng.c:758-769 on the staged raster (as xpnghip_encode_tiles).
+ *   xpnghip_image_fetch               staged raster -> host (w*h*pxsz_out bytes): the level-7 and single-colour outputs.
+ *   xpnghip_image_end                 releases the staging lock.
+ * One image is staged per process at a time: begin takes a process-wide lock that end releases (begin ... end from
+ * several threads serialise); every call between them returns non-zero after a failure, and end must always be called
+ * once begin has returned 0.
+ * xpnghip_normalize_device is the same rule for a caller whose RGBA raster already lives in HBM: *rewritten = 0 means
+ * the raster is already normal (use d_rgba), 1 means d_out (npx * *pxsz_out bytes, caller-allocated npx*4) holds it. */
+int xpnghip_image_begin(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out);
+int xpnghip_image_single_colour(int *single);
+int xpnghip_image_encode(int mode, uint8_t **blobs, uint64_t *blobs_len);
+int xpnghip_image_fetch(uint8_t *dst);
+void xpnghip_image_end(void);
+int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream);
+
 /* ---- device-resident entry points (bench, multi-GPU sharding, pipelines) ---------------------------
  *
  * A context owns the tile table (libxpng.c:51-83) and every intermediate buffer for one raster

@@ -347,3 +347,28 @@ def test_large_batch_takes_the_wide_path_and_matches(gpu, po):
     for i in range(B):
         assert np.array_equal(d_o[i][: W * H * 4].cpu().numpy().reshape(H, W, 4), base[i % 3]), i
     ctx.close()
+
+
+def test_normalize_rgba_on_device_matches_oracle(gpu, po):
+    """normalize_RGBA (libxpng.c:688-721) as device kernels: hidden colour -> zeroed, opaque -> RGB, translucent -> unchanged;
+    odd pixel counts exercise the tails of the 4-pixel-per-thread kernels."""
+    import torch
+    from xpng_amd.synth import synth_raster
+    rng = np.random.default_rng(3)
+    for (w, h), case in [((301, 203), "hidden"), ((301, 203), "opaque"), ((300, 200), "translucent"), ((7, 5), "hidden"), ((5, 3), "opaque")]:
+        r = synth_raster("noise", w, h, True)
+        if case == "opaque":
+            r[..., 3] = 255
+        elif case == "translucent":
+            r[..., 3] = np.maximum(r[..., 3], 1)
+            r[0, 0, 3] = 200
+        else:
+            r[..., 3] = rng.integers(0, 3, (h, w)) * 127
+        want = np.ascontiguousarray(po.normalize_rgba(r))
+        d_in = torch.from_numpy(r).cuda()
+        d_out = torch.zeros(w * h * 4 + 64, dtype=torch.uint8, device="cuda")
+        pxsz, rewritten = gpu.normalize_device(d_in.data_ptr(), w * h, d_out.data_ptr())
+        assert pxsz == want.shape[2], case
+        got = d_out[: w * h * pxsz].cpu().numpy().reshape(h, w, pxsz) if rewritten else r
+        assert np.array_equal(got, want), case
+        assert rewritten == (case != "translucent"), case

@@ -7,7 +7,7 @@ torch.distributed sharding.  It never falls back to a CPU codec: if the HIP libr
 is visible, compute calls raise.
 """
 from .api import (Context, XpngError, build_native, decode_tiles, device_count, encode_tiles, hip_lib,
-                  host_lib, load, native_paths, store)
+                  host_lib, load, native_paths, normalize_device, store)
 
 __all__ = ["Context", "XpngError", "build_native", "decode_tiles", "device_count", "encode_tiles", "hip_lib",
-           "host_lib", "load", "native_paths", "store"]
+           "host_lib", "load", "native_paths", "normalize_device", "store"]

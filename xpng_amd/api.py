@@ -21,6 +21,8 @@ HIP_SYMBOLS = [
     "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
     "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
     "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range", "xpnghip_ctx_decode_status",
+    "xpnghip_image_begin", "xpnghip_image_single_colour", "xpnghip_image_encode", "xpnghip_image_fetch", "xpnghip_image_end",
+    "xpnghip_normalize_device",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -99,6 +101,8 @@ def hip_lib():
         L.xpnghip_m1_transform_device_batch.argtypes = [vp, C.POINTER(vp), C.c_uint32, u64, u64, vp]
         L.xpnghip_debug_fetch.restype = C.c_int64
         L.xpnghip_debug_fetch.argtypes = [vp, C.c_int, u64, vp, u64]
+        L.xpnghip_normalize_device.restype = C.c_int
+        L.xpnghip_normalize_device.argtypes = [vp, u64, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
         _hip = L
     return _hip
 
@@ -169,6 +173,14 @@ def load(path: str) -> np.ndarray:
     out = np.ctypeslib.as_array(pm.p, shape=(pm.h, pm.w, 3 + int(pm.A))).copy()
     _libc.free(pm.p)
     return out
+
+
+def normalize_device(d_rgba: int, npx: int, d_out: int, stream=0):
+    """normalize_RGBA (libxpng.c:688-721) on a device-resident RGBA raster -> (bytes per pixel, rewritten into d_out?)."""
+    pxsz, rew = C.c_int(0), C.c_int(0)
+    if hip_lib().xpnghip_normalize_device(d_rgba, npx, d_out, C.byref(pxsz), C.byref(rew), stream):
+        raise XpngError("xpnghip_normalize_device: " + _err())
+    return pxsz.value, bool(rew.value)
 
 
 class Context:

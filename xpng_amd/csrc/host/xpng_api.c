@@ -58,7 +58,7 @@ static int normalize_rgba(const xpng_t *in, uint8_t **out, uint64_t *s, _Bool *A
     return 0;
 }
 
-static int all_pixels_equal(const uint8_t *p, uint64_t n, int pxsz) { /* whole-image form of libxpng.c:628-643 */
+static int all_pixels_equal(const uint8_t *p, uint64_t n, int pxsz) { /* whole-image form of libxpng.c:628-643; stops at the first difference */
     for (uint64_t i = 1; i < n; i++) if (memcmp(p, p + i * (uint64_t)pxsz, (size_t)pxsz)) return 0;
     return 1;
 }
@@ -76,50 +76,85 @@ static void print_rate(const char *what, uint64_t workers, uint64_t ns, uint64_t
            (unsigned long)((1e9 / (double)ns) * ((double)pixels / 1e6)));
 }
 
+/* The tile-codec path of xpng_store_T (levels 1 and 2 on a raster of more than 4 bytes): the raster is uploaded once and
+ * normalize_RGBA (libxpng.c:733), the whole-image single-colour test (741-753) and the tile encode (758-769) run on the
+ * device.  The normalised raster comes back to the host only for the outputs that contain it verbatim. */
+static _Bool store_on_device(uint64_t mode, const xpng_t *pm, const char *fn, uint64_t t_start) {
+    int pxsz = 0;
+    if (xpnghip_image_begin(pm->p, pm->w, pm->h, 3 + pm->A, &pxsz)) {
+        fprintf(stderr, "xpng: GPU staging failed: %s\n", xpnghip_last_error());
+        return 1;
+    }
+    const _Bool A = pxsz == 4;
+    const uint64_t s = pm->w * pm->h * (uint64_t)pxsz;
+    _Bool rc = 1;
+    uint8_t hdr[8];
+    uint8_t *raw = NULL, *blobs = NULL;
+    put_u32(hdr, (uint32_t)(pm->w - 1) | ((uint32_t)mode << 24));
+    put_u32(hdr + 4, (uint32_t)(pm->h - 1) | ((uint32_t)A << 24));
+    if (mode == 2) { /* libxpng.c:741-753 */
+        int single = 0;
+        if (xpnghip_image_single_colour(&single)) goto done;
+        if (single) {
+            if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
+            hdr[7] |= 2;
+            rc = write_file(fn, hdr, raw, (uint64_t)pxsz);
+            goto done;
+        }
+    }
+    if (A && mode == 2) { mode = 1; hdr[3] = 1; } /* libxpng.c:755 */
+    if (A && (pm->w < 4 || pm->h < 4)) { /* reference behaviour undefined here (SURVEY.md 4): store uncompressed */
+        if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
+        hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
+        rc = write_file(fn, hdr, raw, s);
+        goto done;
+    }
+    {
+        uint64_t blen = 0;
+        if (xpnghip_image_encode((int)mode, &blobs, &blen)) {
+            fprintf(stderr, "xpng: GPU tile encode failed: %s\n", xpnghip_last_error());
+            goto done;
+        }
+        print_rate("encode", 1, now_ns() - t_start, pm->w * pm->h);
+        if (blen >= s) { /* libxpng.c:771-777 */
+            if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
+            hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
+            rc = write_file(fn, hdr, raw, s);
+        } else rc = write_file(fn, hdr, blobs, blen);
+    }
+done:
+    xpnghip_image_end();
+    free(raw);
+    free(blobs);
+    return rc;
+}
+
 _Bool xpng_store_T(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn) {
     const uint64_t t_start = now_ns();
     (void)T; /* one GPU per process; multi-GPU sharding is driven through xpnghip_encode_device */
     if (!pm || !fn || !pm->p || !pm->w || !pm->h || pm->w > XPNG_MAX_DIM || pm->h > XPNG_MAX_DIM ||
         !(mode == 1 || mode == 2 || mode == 7) || pm->w * pm->h * (3u + pm->A) != pm->s)
         return 1; /* libxpng.c:729-731 */
+    /* Everything that reaches the tile codec is staged on the device.  Level 7 and rasters of at most 4 bytes after
+     * normalisation (i.e. a single pixel) never do: they are handled here, on the host, and need no GPU. */
+    if (mode == 2 && !pm->A && pm->w * pm->h > 1 && all_pixels_equal(pm->p, pm->w * pm->h, 3)) { /* libxpng.c:741-753, RGB input: no GPU needed */
+        uint8_t h1[8];
+        put_u32(h1, (uint32_t)(pm->w - 1) | (2u << 24));
+        put_u32(h1 + 4, (uint32_t)(pm->h - 1));
+        h1[7] |= 2;
+        return write_file(fn, h1, pm->p, 3);
+    }
+    if (mode != 7 && pm->w * pm->h > 1) return store_on_device(mode, pm, fn, t_start);
     uint8_t *owned = NULL;
     uint64_t s;
     _Bool A;
     if (normalize_rgba(pm, &owned, &s, &A)) return 1;
     const uint8_t *raster = owned ? owned : pm->p;
-    const int pxsz = 3 + A;
-    _Bool rc = 1;
     uint8_t hdr[8];
-    if (s <= 4) mode = 7; /* libxpng.c:735 */
+    mode = 7; /* explicit level 7, or s <= 4: libxpng.c:735 */
     put_u32(hdr, (uint32_t)(pm->w - 1) | ((uint32_t)mode << 24));
     put_u32(hdr + 4, (uint32_t)(pm->h - 1) | ((uint32_t)A << 24));
-    if (mode == 7) { rc = write_file(fn, hdr, raster, s); goto done; }
-    if (mode == 2 && all_pixels_equal(raster, pm->w * pm->h, pxsz)) { /* libxpng.c:741-753 */
-        hdr[7] |= 2;
-        rc = write_file(fn, hdr, raster, (uint64_t)pxsz);
-        goto done;
-    }
-    if (A && mode == 2) { mode = 1; hdr[3] = 1; } /* libxpng.c:755 */
-    if (A && (pm->w < 4 || pm->h < 4)) { /* reference behaviour undefined here (SURVEY.md §4): store uncompressed */
-        hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
-        rc = write_file(fn, hdr, raster, s);
-        goto done;
-    }
-    {
-        uint8_t *blobs = NULL;
-        uint64_t blen = 0;
-        if (xpnghip_encode_tiles((int)mode, raster, pm->w, pm->h, pxsz, &blobs, &blen)) {
-            fprintf(stderr, "xpng: GPU tile encode failed: %s\n", xpnghip_last_error());
-            goto done;
-        }
-        print_rate("encode", 1, now_ns() - t_start, pm->w * pm->h);
-        if (blen >= s) { /* libxpng.c:771-777 */
-            hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
-            rc = write_file(fn, hdr, raster, s);
-        } else rc = write_file(fn, hdr, blobs, blen);
-        free(blobs);
-    }
-done:
+    const _Bool rc = write_file(fn, hdr, raster, s);
     free(owned);
     return rc;
 }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +14,7 @@
 
 #include "common.hpp"
 #include "m1_decode.hpp"
+#include "normalize.hpp"
 #include "m1_encode.hpp"
 #include "m2_decode.hpp"
 #include "m2_encode.hpp"
@@ -457,6 +459,106 @@ extern "C" int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w,
     HIPCHK(hipMemcpyAsync(c->d_raster, raster, s, hipMemcpyHostToDevice, c->stream));
     uint64_t len = 0;
     if (xpnghip_encode_device(c, mode, c->d_raster, 0, N, c->d_blobs, &len, nullptr)) return 1;
+    uint8_t *out = (uint8_t *)malloc(len ? len : 1);
+    if (!out) return fail("malloc failed");
+    HIPCHK(hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost));
+    *blobs = out; *blobs_len = len;
+    return 0;
+}
+
+// ---- staged image (normalize_RGBA and the single-colour test on the device) ---------------------------
+static uint32_t *g_flags = nullptr;  // 4 device words for the OR-reductions
+static int norm_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, hipStream_t s) {
+    if (!g_flags) HIPCHK(hipMalloc((void **)&g_flags, 16));
+    HIPCHK(hipMemsetAsync(g_flags, 0, 16, s));
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((npx / 4 + 255) / 256 + 1, 256 * 16);
+    k_norm_flags<<<blocks, 256, 0, s>>>((const uint32_t *)d_rgba, npx, g_flags);
+    uint32_t f[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(f, g_flags, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *pxsz_out = 4; *rewritten = 0;
+    if (f[0]) { k_norm_zero_hidden<<<blocks, 256, 0, s>>>((const uint32_t *)d_rgba, (uint32_t *)d_out, npx); *rewritten = 1; }
+    else if (!f[1]) { k_norm_to_rgb<<<blocks, 256, 0, s>>>((const uint32_t *)d_rgba, (uint8_t *)d_out, npx); *pxsz_out = 3; *rewritten = 1; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream) {
+    if (!d_rgba || !d_out || !pxsz_out || !rewritten || !npx) return fail("null argument");
+    if (((uintptr_t)d_rgba & 15) || ((uintptr_t)d_out & 3)) return fail("device buffers must be 16-byte aligned");
+    std::lock_guard<std::mutex> lk(g_mu);
+    return norm_device(d_rgba, npx, d_out, pxsz_out, rewritten, (hipStream_t)stream);
+}
+
+static struct Staged {
+    bool open = false, failed = false;
+    uint64_t w = 0, h = 0, cap_in = 0, cap_norm = 0;
+    int pxsz = 0;
+    uint8_t *d_in = nullptr, *d_norm = nullptr;  // uploaded raster; rewritten raster (when normalisation changed it)
+    const uint8_t *cur = nullptr;                // the staged (normalised) raster
+} g_img;
+
+extern "C" int xpnghip_image_begin(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
+    if (!raster || !pxsz_out || !w || !h || (pxsz_in != 3 && pxsz_in != 4)) return fail("bad argument");
+    g_mu.lock();
+    auto bail = [&](const char *m) { g_mu.unlock(); return fail(m); };
+    int dev = 0;
+    if (xpnghip_device_count() < 1 || hipGetDevice(&dev) != hipSuccess) return bail("no HIP device");
+    const uint64_t s = w * h * (uint64_t)pxsz_in;
+    if (g_img.cap_in < s) {
+        if (g_img.d_in) (void)hipFree(g_img.d_in);
+        g_img.d_in = nullptr; g_img.cap_in = 0;
+        if (hipMalloc((void **)&g_img.d_in, s + 64) != hipSuccess) return bail("hipMalloc failed (staged raster)");
+        g_img.cap_in = s;
+    }
+    if (hipMemcpy(g_img.d_in, raster, s, hipMemcpyHostToDevice) != hipSuccess) return bail("raster upload failed");
+    g_img.w = w; g_img.h = h; g_img.pxsz = pxsz_in; g_img.cur = g_img.d_in; g_img.failed = false;
+    if (pxsz_in == 4) {
+        if (g_img.cap_norm < s) {
+            if (g_img.d_norm) (void)hipFree(g_img.d_norm);
+            g_img.d_norm = nullptr; g_img.cap_norm = 0;
+            if (hipMalloc((void **)&g_img.d_norm, s + 64) != hipSuccess) return bail("hipMalloc failed (normalised raster)");
+            g_img.cap_norm = s;
+        }
+        int rewritten = 0;
+        if (norm_device(g_img.d_in, w * h, g_img.d_norm, &g_img.pxsz, &rewritten, nullptr)) { g_mu.unlock(); return 1; }
+        if (rewritten) g_img.cur = g_img.d_norm;
+    }
+    *pxsz_out = g_img.pxsz;
+    g_img.open = true;
+    return 0;  // (the lock stays held until xpnghip_image_end)
+}
+extern "C" void xpnghip_image_end(void) {
+    if (!g_img.open) return;
+    g_img.open = false;
+    g_mu.unlock();
+}
+extern "C" int xpnghip_image_single_colour(int *single) {
+    if (!g_img.open || !single) return fail("no staged image");
+    const uint64_t n = g_img.w * g_img.h;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+    if (!g_flags) HIPCHK(hipMalloc((void **)&g_flags, 16));
+    HIPCHK(hipMemsetAsync(g_flags + 2, 0, 4, nullptr));
+    if (g_img.pxsz == 4) k_any_differs<4><<<blocks, 256>>>(g_img.cur, n, g_flags + 2);
+    else k_any_differs<3><<<blocks, 256>>>(g_img.cur, n, g_flags + 2);
+    uint32_t f = 0;
+    HIPCHK(hipMemcpy(&f, g_flags + 2, 4, hipMemcpyDeviceToHost));
+    *single = f ? 0 : 1;
+    return 0;
+}
+extern "C" int xpnghip_image_fetch(uint8_t *dst) {
+    if (!g_img.open || !dst) return fail("no staged image");
+    HIPCHK(hipMemcpy(dst, g_img.cur, g_img.w * g_img.h * (uint64_t)g_img.pxsz, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int xpnghip_image_encode(int mode, uint8_t **blobs, uint64_t *blobs_len) {
+    if (!g_img.open || !blobs || !blobs_len) return fail("no staged image");
+    xpnghip_ctx *c = cached_ctx(g_img.w, g_img.h, g_img.pxsz);
+    if (!c) return 1;
+    const uint64_t N = c->tiles.size(), bound = xpnghip_ctx_blob_bound(c, 0, N);
+    if (!c->d_blobs) HIPCHK(hipMalloc((void **)&c->d_blobs, bound + 64));
+    HIPCHK(hipDeviceSynchronize());  // (staging ran on the null stream)
+    uint64_t len = 0;
+    if (xpnghip_encode_device(c, mode, g_img.cur, 0, N, c->d_blobs, &len, nullptr)) return 1;
     uint8_t *out = (uint8_t *)malloc(len ? len : 1);
     if (!out) return fail("malloc failed");
     HIPCHK(hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost));
