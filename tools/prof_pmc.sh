@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-64}
 run() { # tag counters...
   tag=$1; shift
-  timeout -k 10 500 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- \
+  timeout -k 10 500 rocprofv3 --kernel-include-regex "xpng" --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- \
     python3 $R/bench.py --no-cpu --batch $B --pipeline 1 --steps 1 --warmup 1 --roofline-reps 1 > $R/gpurun_out/pmc_$tag.log 2>&1
   echo "pass $tag done"
 }

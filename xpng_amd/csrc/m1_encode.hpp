@@ -153,24 +153,31 @@ __device__ __forceinline__ uint32_t swar_zigzag8(uint32_t d) {  // per byte: v =
     return ((d << 1) & 0xFEFEFEFEu) ^ ((sgn << 8) - sgn);
 }
 // interior pixel (row > 0, column > 0): returns the zig-zag word (zr | zg<<8 | zb<<16 | za<<24) and nl.
+// col0: the pixel is in column 0 of its tile (row > 0): every channel predicts from U and the green subtraction is skipped
+// (libxpng.c:505-513; it applies to interior pixels only).
 template <int useGrad, int useG>
-__device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, uint32_t &nl) {
+__device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, uint32_t &nl, bool col0 = false) {
     uint32_t pred;
     if (!useGrad) {
         pred = __builtin_amdgcn_lerp(L, U, 0x01010101u);  // per byte (L + U + 1) >> 1   (p2a)
-    } else {                                               // p3a per colour channel, low 8 bits
-        pred = 0;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int l = (L >> (8 * c)) & 255, u = (U >> (8 * c)) & 255, ul = (UL >> (8 * c)) & 255;
-            pred |= ((uint32_t)pred_grad(l, u, ul) & 255u) << (8 * c);
-        }
+    } else {
+        // p3a = ((3L + 3U - 2UL) + 2) >> 2 (arithmetic), low 8 bits.  r and b together as two 16-bit lanes: adding 1024 keeps
+        // every lane positive (range -508 .. 1532) and, being a multiple of 4 * 256, leaves the low 8 bits of the shifted
+        // value unchanged; g alone in a 32-bit register with a plain arithmetic shift.
+        const uint32_t Le = L & 0x00FF00FFu, Ue = U & 0x00FF00FFu, ULe = UL & 0x00FF00FFu;
+        const uint32_t te = (Le + Ue) * 3u + 0x04020402u - 2u * ULe;
+        const uint32_t pe = (te >> 2) & 0x00FF00FFu;
+        const int lg = (int)((L >> 8) & 255u), ug = (int)((U >> 8) & 255u), ulg = (int)((UL >> 8) & 255u);
+        const uint32_t pg = (uint32_t)(((lg + ug) * 3 - 2 * ulg + 2) >> 2) & 255u;
+        pred = pe | (pg << 8);
     }
     pred = (pred & 0x00FFFFFFu) | (L & 0xFF000000u);  // alpha always predicts from the left (libxpng.c:511)
+    pred = col0 ? U : pred;
     uint32_t d = swar_sub8(cur, pred);
     if (useG) {                                        // r -= g, b -= g on the residuals (libxpng.c:513)
         const uint32_t g = (d >> 8) & 0xFFu;
-        d = swar_sub8(d, g | (g << 16));
+        const uint32_t dg = swar_sub8(d, g | (g << 16));
+        d = col0 ? d : dg;
     }
     uint32_t z = swar_zigzag8(d);
     const uint32_t m = (z | (z >> 8) | (z >> 16)) & 0xFFu;
@@ -212,10 +219,13 @@ __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const Tile
 #pragma unroll
                 for (int k = 0; k < 4; k++) { c[k + 1] = rowc[x + k]; u[k + 1] = row0 ? 0u : rowu[x + k]; }
             }
-            if (!row0 && x > 0) {  // interior group: byte-parallel arithmetic, then a 4x4 byte transpose into the planes
+            if (!row0) {  // rows below the first: byte-parallel arithmetic, then a 4x4 byte transpose into the planes.  (A group
+                          // at x == 0 goes this way too: nearly every wave holds one, and the scalar path would cost the whole
+                          // wave its ~170 instructions.)
                 uint32_t z[4], n4[4];
+                z[0] = m1_pixel_interior<useGrad, useG>(c[1], c[0], u[1], u[0], n4[0], x == 0);
 #pragma unroll
-                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior<useGrad, useG>(c[k + 1], c[k], u[k + 1], u[k], n4[k]);
+                for (int k = 1; k < 4; k++) z[k] = m1_pixel_interior<useGrad, useG>(c[k + 1], c[k], u[k + 1], u[k], n4[k]);
                 onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
                 const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);  // z0.b0 z1.b0 z0.b1 z1.b1
                 const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);  // z0.b2 z1.b2 z0.b3 z1.b3
