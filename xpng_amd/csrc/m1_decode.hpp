@@ -502,7 +502,8 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
                                                       uint8_t *__restrict__ nlseq) {
     __shared__ u32x4_t head[10 * 64];
-    __shared__ uint32_t ringw[10 * 16 * 64];
+    constexpr uint32_t WCH = 8, SVC = 4, WDW = WCH * 4;  // window: 8 chunks of 16 B = 32 dwords per queue; a queue is serviced every 4th block
+    __shared__ uint32_t ringw[10 * WDW * 64];
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 64 + lane;
     bool live = j < total_tiles;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     const uintptr_t base = (uintptr_t)(ctxsym + t->pbase);
     uint8_t *out = nlseq + t->pbase;
     uint32_t qoff[9], have[9];
-    u32x4_t fl[9];
+    u32x4_t fl[9][SVC];  // in flight per queue: chunks have .. have + SVC - 1
     typedef const __attribute__((address_space(1))) u32x4_t *gp128;
     const u32x4_t zero4 = {0, 0, 0, 0};
 #pragma unroll
@@ -521,19 +522,19 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
         qoff[c] = live ? d->ctx_start[c] : 0;
         const gp128 src = (gp128)(base + qoff[c]);
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < (int)SVC; q++) {
             u32x4_t v = zero4;
             if (live) v = src[q];
-            ringw[(c * 16 + q * 4 + 0) * 64 + lane] = v.x; ringw[(c * 16 + q * 4 + 1) * 64 + lane] = v.y;
-            ringw[(c * 16 + q * 4 + 2) * 64 + lane] = v.z; ringw[(c * 16 + q * 4 + 3) * 64 + lane] = v.w;
+            ringw[(c * WDW + q * 4 + 0) * 64 + lane] = v.x; ringw[(c * WDW + q * 4 + 1) * 64 + lane] = v.y;
+            ringw[(c * WDW + q * 4 + 2) * 64 + lane] = v.z; ringw[(c * WDW + q * 4 + 3) * 64 + lane] = v.w;
             if (q == 0) { const u32x4_t h = {v.x, 0u, v.y, 0u}; head[c * 64 + lane] = h; }
         }
-        have[c] = 3;
-        fl[c] = zero4;
-        if (live) fl[c] = src[3];  // in flight: lands at the first boundary
+        have[c] = SVC;
+#pragma unroll
+        for (int q = 0; q < (int)SVC; q++) { fl[c][q] = zero4; if (live) fl[c][q] = src[SVC + q]; }
     }
 #pragma unroll
-    for (int w = 0; w < 16; w++) ringw[(9 * 16 + w) * 64 + lane] = 0x09090909u;
+    for (int w = 0; w < (int)WDW; w++) ringw[(9 * WDW + w) * 64 + lane] = 0x09090909u;
     { const u32x4_t h = {0x09090909u, 0u, 0x09090909u, 0u}; head[9 * 64 + lane] = h; }
     uint32_t T = total;
 #pragma unroll
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     uint32_t cur = total > 0 ? 0u : 9u;
     // registers of the previous step: its queue and the head it popped from (lo, pos, nxt); queue 9 at start (harmless)
     uint32_t pcur = 9, plo = 0x09090909u, ppos = 0, pnxt = 0x09090909u;
-    for (uint32_t kb = 0; kb < T; kb += 16) {
+    auto block = [&](uint32_t kb) __attribute__((always_inline)) {
         uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
             // flight together
             const uint32_t npos = ppos + 1;
             const bool cross = (npos & 3u) == 0;
-            const uint32_t rr = ringw[(pcur * 16 + (((npos >> 2) + 1) & 15u)) * 64 + lane];
+            const uint32_t rr = ringw[(pcur * WDW + (((npos >> 2) + 1) & (WDW - 1))) * 64 + lane];
             const u32x4_t r = head[cur * 64 + lane];               // (stale if cur == pcur: forwarded below)
             const uint32_t nlo = cross ? pnxt : plo >> 8, nnxt = cross ? rr : pnxt;
             { const u32x4_t h = {nlo, npos, nnxt, 0u}; head[pcur * 64 + lane] = h; }
@@ -562,18 +563,39 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
             cur = kb + (uint32_t)u + 1 >= total ? 9u : (sym < 9u ? sym : 9u);  // (symbols > 8 only in corrupt streams)
         }
         if (kb < total) *reinterpret_cast<uint4 *>(out + kb) = make_uint4(o[0], o[1], o[2], o[3]);
-        // ---- boundary: the chunk requested 16 steps ago lands if its window slot has been read out (the window then
-        // holds >= 32 unread bytes, two blocks' worth); either way the next missing chunk is requested again.
-        // (The head of queue pcur in LDS is one pop behind the registers; a chunk index can only be underestimated by that.)
+    };
+    // Service of the queues of one phase, every SVC-th block boundary (so a request has 64 steps, not 16, to come back: 64
+    // lanes x 9 queues are 576 different cache lines per round, and a round asks for whole 64-byte lines).  Up to SVC
+    // chunks land while their window slots have been read out; after a service the window holds >= 16 * SVC unread bytes
+    // (SVC blocks' worth) or everything up to its capacity; the next SVC missing chunks are requested again either way.
+    // (The head of queue pcur in LDS is one pop behind the registers; a chunk index can only be underestimated by that.)
+    auto service = [&](int phase) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < 9; c++) {
+            if ((c & (int)(SVC - 1)) != phase) continue;
             const uint32_t cq = head[c * 64 + lane].y >> 4;  // chunk the queue is reading from
-            if (have[c] - cq < 4) {
-                const uint32_t w0 = (c * 16 + (have[c] & 3u) * 4) * 64 + lane;
-                ringw[w0] = fl[c].x; ringw[w0 + 64] = fl[c].y; ringw[w0 + 128] = fl[c].z; ringw[w0 + 192] = fl[c].w;
-                have[c]++;
+#pragma unroll
+            for (int q = 0; q < (int)SVC; q++) {
+                if (have[c] - cq < WCH) {  // (once one chunk does not fit, neither do the later ones: have stops growing)
+                    const uint32_t w0 = (c * WDW + (have[c] & (WCH - 1)) * 4) * 64 + lane;
+                    ringw[w0] = fl[c][q].x; ringw[w0 + 64] = fl[c][q].y; ringw[w0 + 128] = fl[c][q].z; ringw[w0 + 192] = fl[c][q].w;
+                    have[c]++;
+                }
             }
-            if (live) fl[c] = ((gp128)(base + qoff[c]))[have[c]];
+            if (live) {
+                const gp128 src = (gp128)(base + qoff[c]) + have[c];
+#pragma unroll
+                for (int q = 0; q < (int)SVC; q++) fl[c][q] = src[q];
+            }
+        }
+    };
+    for (uint32_t kb = 0; kb < T; kb += 16 * SVC) {
+#pragma unroll
+        for (int ph = 0; ph < (int)SVC; ph++) {
+            if (kb + 16 * ph < T) {
+                block(kb + 16 * ph);
+                service(ph);
+            }
         }
     }
 }
