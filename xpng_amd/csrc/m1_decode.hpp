@@ -43,10 +43,10 @@ struct DecodeWs {
     DecTile *d_info = nullptr;
     uint64_t *d_off = nullptr;
     uint8_t *d_ctxsym = nullptr, *d_asym = nullptr, *d_alpha = nullptr, *d_nlseq = nullptr;
-    uint32_t *d_resid = nullptr;
+    uint32_t *d_resid = nullptr, *d_resid_alloc = nullptr;  // d_resid = d_resid_alloc + 16: k_dec_recon_band reads up to 3 words before a tile's first
 };
 inline void decode_ws_free(DecodeWs &w) {
-    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid, w.d_wdec, w.d_dtab};
+    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc, w.d_wdec, w.d_dtab};
     for (void *q : p) if (q) (void)hipFree(q);
     if (w.side) (void)hipStreamDestroy(w.side);
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
@@ -848,6 +848,95 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------------
+// Reconstruction for large batches: ONE wavefront per tile (k_dec_recon spreads a tile over up to 9 waves that hand rows
+// to each other through LDS and progress counters: right for one image, but with thousands of tiles in flight the
+// per-step hand-over latency, not the arithmetic, sets the pace).  The tile is swept in bands of 64 rows; lane r owns row
+// yb + r and at step s reconstructs column s - r, so its U is what lane r-1 produced one step earlier (DPP wave_shr:1),
+// its UL its previous U and its L its own previous output: no LDS, no synchronisation inside a band.  Lane 63 leaves its
+// row in a seam buffer for lane 0 of the next band.  All four channels move through one register (v_lerp_u8 average,
+// 16-bit-lane gradient, byte-parallel add); residual words arrive as one 16-byte load per lane every 4 steps and pixels
+// leave as one 16-byte store (single dwords at the two ends of a row).  RGBA only.
+constexpr uint32_t RB_MAXW = 2048;  // seam buffer, pixels
+__device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-byte a + b (mod 256)
+    return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
+}
+__global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
+                                                       TileSel sel, const uint32_t *__restrict__ resid,
+                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags) {
+    __shared__ uint32_t seam[RB_MAXW];
+    const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
+    const DecTile *d = info + j;
+    const uint32_t type = d->type;
+    if (type == TILE_BAD) return;
+    const TileDesc t = tiles[vtile(sel, j)];
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * 4;
+    if (type == 0) {  // raw rows (libxpng.c:846)
+        const uint8_t *src = d->blob + 4;
+        const uint64_t row = (uint64_t)t.w * 4;
+        for (uint64_t b = lane; b < row * t.h; b += 64) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+        return;
+    }
+    const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
+    const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | ((kw0 & 255u) << 24);
+    const bool grad = (type >> 1) & 1;
+    const uint32_t *rs = resid + t.pbase;
+    const int32_t w = (int32_t)t.w;
+    typedef uint32_t u32x4_a4r __attribute__((ext_vector_type(4), aligned(4)));
+    for (uint32_t yb = 0; yb < t.h; yb += 64) {
+        const uint32_t y = yb + lane;
+        const bool active = y < t.h;
+        // (a lane reads up to 63 words before and 70 after its row: inside the tile's words, or the slack of the buffer; never used)
+        const uint32_t *rsrow = rs + (active ? (uint64_t)y * t.w : (uint64_t)lane);
+        uint8_t *drow = dst + (uint64_t)(active ? y : 0) * bpr;
+        const uint32_t S = t.w + 63;
+        uint32_t prev = 0, U = 0, ev = 0;
+        u32x4_a4r nxt = *reinterpret_cast<const u32x4_a4r *>(rsrow - (int32_t)lane);
+        for (uint32_t s = 0; s < S; s += 4) {
+            const u32x4_a4r cur4 = nxt;
+            nxt = *reinterpret_cast<const u32x4_a4r *>(rsrow + ((int32_t)s + 4 - (int32_t)lane));
+            if (yb > 0 && (s & 63u) == 0 && (int32_t)s < w) ev = (int32_t)(s + lane) < w ? seam[s + lane] : 0u;  // next 64 columns of the row above the band
+            const uint32_t rwv[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+            uint32_t o[4];
+            const int32_t x0 = (int32_t)s - (int32_t)lane;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // previous-step output of the lane above (lane 0: the seam row)
+                uint32_t Unew = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)prev, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)((s + k) & 63u));
+                Unew = lane == 0 ? e0 : Unew;
+                const int32_t x = x0 + k;
+                const bool on = active && x >= 0 && x < w;
+                const uint32_t rw = rwv[k];
+                const uint32_t nUL = U, nU = Unew;
+                uint32_t pred;
+                if (!grad) pred = __builtin_amdgcn_lerp(prev, nU, 0x01010101u);  // per byte (L + U + 1) >> 1
+                else {
+                    const uint32_t Le = prev & 0x00FF00FFu, Ue = nU & 0x00FF00FFu, ULe = nUL & 0x00FF00FFu;
+                    const uint32_t pe = (((Le + Ue) * 3u + 0x04020402u - 2u * ULe) >> 2) & 0x00FF00FFu;
+                    const int lg = (int)((prev >> 8) & 255u), ug = (int)((nU >> 8) & 255u), ulg = (int)((nUL >> 8) & 255u);
+                    pred = pe | (((uint32_t)(((lg + ug) * 3 - 2 * ulg + 2) >> 2) & 255u) << 8);
+                }
+                pred = y == 0 ? prev : pred;   // row 0 predicts from the left,
+                pred = x == 0 ? nU : pred;     // column 0 from above (libxpng.c:805-810)
+                uint32_t px = (swar_add8(rw, pred) & 0x00FFFFFFu) | (rw & 0xFF000000u);  // alpha travels in the residual word
+                px = (rw >> 24) ? px : 0u;     // alpha == 0: the whole pixel is 0 (libxpng.c:802)
+                px = (y | (uint32_t)x) == 0 ? first : px;
+                if (on) { U = nU; prev = px; }
+                o[k] = px;
+                if (lane == 63 && on) seam[x] = px;  // (a full band: lane 63 is an existing row)
+            }
+            if (dbgflags & 1) { if (lane == 0 && x0 >= 0 && x0 + 3 < w) *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]}; }
+            else if (active && x0 >= 0 && x0 + 3 < w) {
+                *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]};
+            } else if (active) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int32_t x = x0 + k; if (x >= 0 && x < w) *reinterpret_cast<uint32_t *>(drow + 4ll * x) = o[k]; }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // (re)allocate the decode workspace and bring the tile offsets to the device
 inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane, const uint64_t *tile_off, uint32_t t0,
                              uint32_t total, hipStream_t s, std::string &err) {
@@ -857,10 +946,11 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
         if (hipMalloc((void **)&ws.d_info, (uint64_t)B * n_tiles * sizeof(DecTile)) != hipSuccess || hipMalloc((void **)&ws.d_off, (uint64_t)B * n_tiles * 8) != hipSuccess ||
             hipMalloc((void **)&ws.d_ctxsym, plane + 8192) != hipSuccess || hipMalloc((void **)&ws.d_asym, plane + 64) != hipSuccess ||
             hipMalloc((void **)&ws.d_alpha, plane + 64) != hipSuccess || hipMalloc((void **)&ws.d_nlseq, plane + 64) != hipSuccess ||
-            hipMalloc((void **)&ws.d_resid, 4 * plane + 64) != hipSuccess ||
+            hipMalloc((void **)&ws.d_resid_alloc, 4 * plane + 1024) != hipSuccess ||
             hipMalloc((void **)&ws.d_wdec, (uint64_t)B * n_tiles * 10 * sizeof(WDec)) != hipSuccess ||
             hipMalloc((void **)&ws.d_dtab, (uint64_t)B * n_tiles * 10 * WD_TAB_MAX) != hipSuccess)
             return bad("hipMalloc failed (decode workspace)");
+        ws.d_resid = ws.d_resid_alloc + 16;
         ws.cap_tiles = (uint64_t)B * n_tiles; ws.cap_plane = plane;
     }
     if (ws.last_off.size() != total || ws.last_t0 != t0 || memcmp(ws.last_off.data(), tile_off, (size_t)total * 8) != 0) {
@@ -932,7 +1022,8 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (wide) k_dec_resid<4, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
         else k_dec_resid<4, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, getenv("XPNG_DBG_NOSTORE") ? 1u : 0u);
+        else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
         if (wide) k_dec_resid<3, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
