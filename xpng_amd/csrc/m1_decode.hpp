@@ -589,14 +589,12 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
             }
         }
     };
-    for (uint32_t kb = 0; kb < T; kb += 16 * SVC) {
-#pragma unroll
-        for (int ph = 0; ph < (int)SVC; ph++) {
-            if (kb + 16 * ph < T) {
-                block(kb + 16 * ph);
-                service(ph);
-            }
-        }
+    // (one copy of the 16-step block in the instruction stream, not SVC: the loop body stays at 8 KB, which matters when
+    // kernels of other batches share the CU's instruction cache)
+#pragma unroll 1
+    for (uint32_t kb = 0; kb < T; kb += 16) {
+        block(kb);
+        service((int)((kb >> 4) & (SVC - 1)));
     }
 }
 
