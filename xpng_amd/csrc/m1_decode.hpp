@@ -504,7 +504,8 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     __shared__ u32x4_t head[10 * 64];
     constexpr uint32_t WCH = 8, SVC = 4, WDW = WCH * 4;  // window: 8 chunks of 16 B = 32 dwords per queue; a queue is serviced every 4th block
     __shared__ uint32_t ringw[10 * WDW * 64];
-    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    __builtin_amdgcn_s_setprio(3);
+ // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 64 + lane;
     bool live = j < total_tiles;
     const DecTile *d = info + (live ? j : 0);
