@@ -203,29 +203,31 @@ __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const Tile
         const uint32_t lr = yy + (y0 - first);  // LDS row of pixel row yy
         const uint32_t sh = (uint32_t)(((uint64_t)(t.y + first + lr) * bpr + (uint64_t)t.x * 4) & 15);
         const uint32_t *rowc = reinterpret_cast<const uint32_t *>(rows + lr * TR_PITCH + sh);
-        if (x + 3 < t.w && j0 + 3 < strip_px && (bpr & 15) == 0) {
-            // whole group in one row (and every row has the same 16-byte phase): 5 + 5 dwords
-            const uint32_t *rowu = reinterpret_cast<const uint32_t *>(rows + (lr ? lr - 1 : 0) * TR_PITCH + sh);
-            const bool row0 = (y0 + yy) == 0;
+        const bool whole = x + 3 < t.w;                       // the four pixels share a row
+        const bool row0 = (y0 + yy) == 0;                     // ... and it is the tile's first row (left-only prediction)
+        if (j0 + 3 < strip_px && !row0) {
+            // Rows below the first: byte-parallel arithmetic, then a 4x4 byte transpose into the planes.  Every such group goes
+            // this way, including the one at the start of a row (column 0 predicts from above) and, for tile widths that are not
+            // a multiple of 4, the one that straddles two rows: nearly every wave holds one of those, and the scalar path would
+            // cost the whole wave its ~170 instructions.
             uint32_t c[5], u[5];
-            c[0] = x ? rowc[x - 1] : 0u;
-            u[0] = (x && !row0) ? rowu[x - 1] : 0u;
-            if (sh == 0) {  // 16-byte aligned group: one ds_read_b128 per row (dword reads at a 16-byte lane stride are 4-way bank conflicts)
-                const uint4 cc = *reinterpret_cast<const uint4 *>(rowc + x);
-                const uint4 uu = row0 ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(rowu + x);
-                c[1] = cc.x; c[2] = cc.y; c[3] = cc.z; c[4] = cc.w;
-                u[1] = uu.x; u[2] = uu.y; u[3] = uu.z; u[4] = uu.w;
-            } else {
+            bool col0[4] = {x == 0, false, false, false};
+            if (whole && (bpr & 15) == 0) {
+                const uint32_t *rowu = reinterpret_cast<const uint32_t *>(rows + (lr - 1) * TR_PITCH + sh);
+                c[0] = x ? rowc[x - 1] : 0u;
+                u[0] = x ? rowu[x - 1] : 0u;
+                if (sh == 0) {  // 16-byte aligned group: one ds_read_b128 per row (dword reads at a 16-byte lane stride are 4-way bank conflicts)
+                    const uint4 cc = *reinterpret_cast<const uint4 *>(rowc + x);
+                    const uint4 uu = *reinterpret_cast<const uint4 *>(rowu + x);
+                    c[1] = cc.x; c[2] = cc.y; c[3] = cc.z; c[4] = cc.w;
+                    u[1] = uu.x; u[2] = uu.y; u[3] = uu.z; u[4] = uu.w;
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) { c[k + 1] = rowc[x + k]; u[k + 1] = row0 ? 0u : rowu[x + k]; }
-            }
-            if (!row0) {  // rows below the first: byte-parallel arithmetic, then a 4x4 byte transpose into the planes.  (A group
-                          // at x == 0 goes this way too: nearly every wave holds one, and the scalar path would cost the whole
-                          // wave its ~170 instructions.)
+                    for (int k = 0; k < 4; k++) { c[k + 1] = rowc[x + k]; u[k + 1] = rowu[x + k]; }
+                }
                 uint32_t z[4], n4[4];
-                z[0] = m1_pixel_interior<useGrad, useG>(c[1], c[0], u[1], u[0], n4[0], x == 0);
 #pragma unroll
-                for (int k = 1; k < 4; k++) z[k] = m1_pixel_interior<useGrad, useG>(c[k + 1], c[k], u[k + 1], u[k], n4[k]);
+                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior<useGrad, useG>(c[k + 1], c[k], u[k + 1], u[k], n4[k], col0[k]);
                 onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
                 const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);  // z0.b0 z1.b0 z0.b1 z1.b1
                 const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);  // z0.b2 z1.b2 z0.b3 z1.b3
@@ -236,14 +238,29 @@ __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const Tile
                 ob = __builtin_amdgcn_perm(t23hi, t01hi, 0x05040100u);   // b2
                 oa = __builtin_amdgcn_perm(t23hi, t01hi, 0x07060302u);   // b3
             } else {
+                // gather pixel by pixel: rows may differ inside the group and (image width not a multiple of 4) so may each
+                // row's 16-byte phase
+                const uint32_t ph0 = (uint32_t)(((uint64_t)(t.y + first) * bpr + (uint64_t)t.x * 4) & 15), bl = (uint32_t)(bpr & 15);
+                uint32_t z[4], n4[4], xx = x, ll = lr;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
-                    if (y0 + yy + x + k != 0) m1_pixel<4>(c[k + 1], c[k], u[k + 1], u[k], row0, x + k == 0, useGrad, useG, nl, zr, zg, zb, za);
-                    onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+                    const uint32_t *rc = reinterpret_cast<const uint32_t *>(rows + ll * TR_PITCH + ((ph0 + ll * bl) & 15u));
+                    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rows + (ll - 1) * TR_PITCH + ((ph0 + (ll - 1) * bl) & 15u));
+                    const uint32_t cur = rc[xx], L = xx ? rc[xx - 1] : 0u, U = ru[xx], UL = xx ? ru[xx - 1] : 0u;
+                    z[k] = m1_pixel_interior<useGrad, useG>(cur, L, U, UL, n4[k], xx == 0);
+                    if (++xx == t.w) { xx = 0; ll++; }
                 }
+                onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
+                const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);
+                const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);
+                const uint32_t t23lo = __builtin_amdgcn_perm(z[3], z[2], 0x05010400u);
+                const uint32_t t23hi = __builtin_amdgcn_perm(z[3], z[2], 0x07030602u);
+                orr = __builtin_amdgcn_perm(t23lo, t01lo, 0x05040100u);
+                og = __builtin_amdgcn_perm(t23lo, t01lo, 0x07060302u);
+                ob = __builtin_amdgcn_perm(t23hi, t01hi, 0x05040100u);
+                oa = __builtin_amdgcn_perm(t23hi, t01hi, 0x07060302u);
             }
-        } else {
+        } else {  // the tile's first row and the last, partial group of a strip: pixel by pixel, every case
             uint32_t y = yy;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -254,9 +271,9 @@ __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const Tile
                     const uint32_t s1 = l2 ? (uint32_t)(((uint64_t)(t.y + first + l2 - 1) * bpr + (uint64_t)t.x * 4) & 15) : 0u;
                     const uint32_t *rc = reinterpret_cast<const uint32_t *>(rows + l2 * TR_PITCH + s2);
                     const uint32_t *ru = reinterpret_cast<const uint32_t *>(rows + (l2 ? l2 - 1 : 0) * TR_PITCH + s1);
-                    const bool row0 = (y0 + y) == 0, col0 = x == 0;
-                    const uint32_t cur = rc[x], L = col0 ? 0u : rc[x - 1], U = row0 ? 0u : ru[x], UL = (row0 || col0) ? 0u : ru[x - 1];
-                    m1_pixel<4>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
+                    const bool r0 = (y0 + y) == 0, c0 = x == 0;
+                    const uint32_t cur = rc[x], L = c0 ? 0u : rc[x - 1], U = r0 ? 0u : ru[x], UL = (r0 || c0) ? 0u : ru[x - 1];
+                    m1_pixel<4>(cur, L, U, UL, r0, c0, useGrad, useG, nl, zr, zg, zb, za);
                 }
                 onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
                 if (++x == t.w) { x = 0; y++; }

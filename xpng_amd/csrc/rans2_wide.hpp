@@ -7,10 +7,8 @@
 //   k_rans2_prep    wave per (tile, stream): histogram -> alphabet -> tables (rans_* helpers of rans2.hpp); empty and
 //                   one-symbol blocks are finished on the spot; otherwise the encoder table and the normalised
 //                   frequencies go to global memory
-//   k_rans2_chain   wave per WIDE_TILES tiles: lane = one rANS state of one stream (2 x streams lanes per tile).  Tables in
-//                   LDS; each lane streams its own symbols through a register window straight from global memory; the
-//                   spill position inside a pair comes from a DPP lane swap (state0's word first); words go straight to
-//                   the block's word area.  The wave runs for its longest chain.
+//   k_rans2_chain2  lane = one rANS state; a wave carries the same stream class of 16 (alpha) or 32 (context) tiles, so the
+//                   chains of one wave have similar lengths; block-synchronous (see the kernel)
 //   k_rans2_finish  wave per (tile, stream): states, header, frequency table, type-2 (raw) fallback
 #pragma once
 #include "common.hpp"
@@ -18,7 +16,6 @@
 
 namespace xpng {
 
-constexpr uint32_t WIDE_TILES = 3;
 constexpr uint32_t WTAB_TILE_BYTES = 4096 + 9 * 256;  // alpha table (256 x 16 B) + nine context tables (16 x 16 B)
 struct WPrep {
     uint32_t kind;  // 0 = block already final (size in `cnt`), 1 = needs chain + finish
@@ -65,81 +62,6 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     uint16_t *gF = wF + ((uint64_t)tile * 10 + c) * 256;
     for (uint32_t i = lane; i < N; i += 64) { gt[i] = tab[i]; gF[i] = (uint16_t)hist[i]; }
     if (lane == 0) *p = WPrep{1, N, distinct, 0, {0, 0}};
-}
-
-__global__ __launch_bounds__(64) void k_rans2_chain(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total, uint32_t spt,
-                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
-                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                    WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
-    __shared__ __align__(16) uint8_t ltab[WIDE_TILES * WTAB_TILE_BYTES];
-    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
-    const uint32_t lane = threadIdx.x & 63, lpt = 2 * spt;  // lanes per tile
-    const uint32_t tsel = lane / lpt, r = lane - tsel * lpt, c = r >> 1, par = r & 1;
-    const uint32_t j = blockIdx.x * WIDE_TILES + tsel;
-    bool live = tsel < WIDE_TILES && j < total;
-    const uint32_t tile = live ? vtile(sel, j) : vtile(sel, 0);
-    // tables of the wave's tiles -> LDS (whole 6.4 KB records; unused entries are never read)
-    for (uint32_t ts = 0; ts < WIDE_TILES; ts++) {
-        const uint32_t jj = blockIdx.x * WIDE_TILES + ts;
-        if (jj >= total) break;
-        const uint4 *src = reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES);
-        uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * WTAB_TILE_BYTES);
-        for (uint32_t i = lane; i < WTAB_TILE_BYTES / 16; i += 64) dst[i] = src[i];
-    }
-    __syncthreads();
-    const TileDesc t = tiles[tile];
-    uint8_t *sc = scratch + t.sbase;
-    const uint8_t *in;
-    uint32_t n;
-    int pb;
-    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = live ? ctx_n[(uint64_t)tile * 9 + c] : 0; pb = 12; }
-    else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; pb = 15; }
-    WPrep *p = prep + (uint64_t)tile * 10 + c;
-    live = live && p->kind == 1;
-    const uint32_t mysteps = live ? ((n + 1 - par) >> 1) : 0;  // state0 codes ceil(n/2) symbols, state1 floor(n/2)
-    uint32_t maxsteps = mysteps;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(maxsteps, o); maxsteps = v > maxsteps ? v : maxsteps; }
-    maxsteps = sgpr(maxsteps);
-    const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (tsel < WIDE_TILES ? tsel : 0) * WTAB_TILE_BYTES + wtab_off(c));
-    uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t.n, (int)c)) + 3;
-    // per-lane symbol window: 4 of this lane's (stride-2) symbols per 8-byte chunk, one chunk prefetched
-    const uintptr_t A = (uintptr_t)(in + par);
-    const uint64_t *chunk = reinterpret_cast<const uint64_t *>(A & ~(uintptr_t)7);
-    const uint32_t off = (uint32_t)(A & 7), bp8 = (off & 1) * 8;
-    uint64_t win = live ? (chunk[0] >> bp8) >> (16 * (off >> 1)) : 0;
-    uint32_t have = 4 - (off >> 1);
-    uint64_t nxt = live ? chunk[1] : 0;
-    chunk += 2;
-    uint32_t fetched = 0;  // symbols handed out so far (a lane stops loading once its own chain is covered)
-    auto next_sym = [&]() -> uint32_t {
-        const uint32_t sy = (uint32_t)win & 0xFFu;
-        win >>= 16;
-        fetched++;
-        if (--have == 0) { win = nxt >> bp8; have = 4; if (fetched < mysteps) nxt = *chunk; chunk++; }
-        return sy;
-    };
-    const uint32_t cmpl_base = 1u << pb;
-    const int thr_shift = 31 - pb;
-    uint64_t s = RANS_L;
-    uint32_t cnt = 0;
-    EncSym e = tab[next_sym()];
-    for (uint32_t k = 0; k < maxsteps; k++) {
-        const EncSym en = tab[next_sym()];  // table entry of the NEXT step: its LDS latency hides under this step's arithmetic
-        const bool act = k < mysteps;
-        const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
-        const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
-        const uint32_t other = swap_pair(emit);
-        if (emit) { w[cnt + (par ? other : 0u)] = (uint32_t)s; s >>= 32; }  // state0's word first (libxpng.c:370-373)
-        cnt += emit + other;
-        if (act) {
-            const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
-            const uint64_t q = __umul64hi(s, rcp) >> rsh;
-            s += e.bias + q * (uint64_t)(cmpl_base - freq);
-        }
-        e = en;
-    }
-    if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
 }
 
 // Block-synchronous form of the chain, packed by stream class (BIG: the alpha streams of 16 tiles, 32 lanes; else

@@ -302,8 +302,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
         k_rans2_prep<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        if (getenv("XPNG_MIXED_CHAIN")) k_rans2_chain<<<(total + WIDE_TILES - 1) / WIDE_TILES, 64, 0, s>>>(c->d_tiles, sel, total, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
-        else {
+        {
             // the alpha chains are the longest: they run on their own stream beside the context chains
             if (PXSZ == 4) {
                 if (!c->enc_side) {
