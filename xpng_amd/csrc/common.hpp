@@ -19,10 +19,19 @@ struct TileDesc {
     uint64_t sbase;       // byte offset of this tile's stream scratch (multiple of 256)
 };
 
-// A launch covers tiles [t0, t0 + cnt) of EVERY image of the batch.  Work item j in [0, B*cnt) maps to image j / cnt and
-// to entry vtile(j) of the (B * N)-entry tile table.
-struct TileSel { uint32_t t0, cnt, N; };
-__host__ __device__ inline uint32_t vtile(const TileSel &s, uint32_t j) { return (j / s.cnt) * s.N + s.t0 + (j % s.cnt); }
+// A launch covers tiles [t0, t0 + cnt) of EVERY image of the batch (nimg images).  Work item j in [0, nimg*cnt) maps to
+// entry vtile(j) of the (B * N)-entry tile table:
+//   order == nullptr : image-major, image j / cnt, tile t0 + j % cnt
+//   order != nullptr : tile-major over order[] (the cnt tile indices sorted by decreasing pixel count): tile order[j / nimg],
+//                      image j % nimg.  Neighbouring work items then have chains of equal length (the wide kernels put
+//                      32-64 of them in one wavefront, which runs for its longest), and the biggest tiles come first.
+// Per-tile outputs that the host sees per image (sizes, offsets) are indexed by imglin() = image * cnt + (tile - t0).
+struct TileSel { uint32_t t0, cnt, N, nimg; const uint32_t *order; };
+__host__ __device__ inline uint32_t vtile(const TileSel &s, uint32_t j) {
+    if (s.order) { const uint32_t r = j / s.nimg; return (j - r * s.nimg) * s.N + s.order[r]; }
+    return (j / s.cnt) * s.N + s.t0 + (j % s.cnt);
+}
+__host__ __device__ inline uint32_t imglin(const TileSel &s, uint32_t vt) { const uint32_t img = vt / s.N; return img * s.cnt + (vt - img * s.N - s.t0); }
 
 // Stream-scratch layout of one tile, all offsets relative to TileDesc::sbase and derived from n only,
 // so that host and device agree without a table.  Capacities are worst cases:

@@ -92,10 +92,11 @@ __global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint
                             uint32_t *__restrict__ status) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
-    const TileDesc t = tiles[vtile(sel, j)];
+    const uint32_t vt = vtile(sel, j), il = imglin(sel, vt);  // off[] is image-major (host order)
+    const TileDesc t = tiles[vt];
     DecTile d{};
-    d.blob = blobs[j / cnt] + off[j];
-    const uint64_t avail = blob_len[j / cnt] > off[j] ? blob_len[j / cnt] - off[j] : 0;
+    d.blob = blobs[t.img] + off[il];
+    const uint64_t avail = blob_len[t.img] > off[il] ? blob_len[t.img] - off[il] : 0;
     const uint8_t *f = d.blob;
     bool ok = avail >= 4;
     uint32_t L = 0;
@@ -975,9 +976,10 @@ inline void recon_geometry(uint32_t max_w, uint32_t max_h, uint32_t &free_ew, ui
 inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
                             uint32_t max_w, uint32_t max_h, int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *d_blob_len,
                             uint32_t *d_status, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
-                            uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr) {
+                            uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr,
+                            const uint32_t *d_order = nullptr) {
     const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
-    const TileSel sel{t0, cnt, (uint32_t)n_tiles};
+    const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
     if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err)) return 1;

@@ -386,7 +386,7 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                             uint8_t *const *d_raster_ptrs, M2DecTile *d_info2, M2Blk *d_blk2, uint16_t *d_tabs2, uint8_t *d_scratch2,
                             const uint64_t *d_sbase2, hipStream_t s, std::string &err) {
     const uint32_t cnt = t1 - t0, total = B * cnt;
-    const TileSel sel{t0, cnt, (uint32_t)n_tiles};
+    const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, nullptr};
     if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err)) return 1;
     const uint64_t bpr = W * 3;
     if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }

@@ -45,8 +45,9 @@ __global__ void k_tile_sizes(const TileDesc *__restrict__ tiles, TileSel sel, ui
     for (uint32_t c = 0; c < spt; c++) fsz += blk_sz[(uint64_t)tile * 10 + c];
     const uint64_t raw = (uint64_t)t.n * pxsz + 4;
     const int pr = pr_from_sums(sums + (uint64_t)tile * 4, pxsz, t.w, t.h);
-    if (fsz < raw) { tile_sz[j] = (uint32_t)fsz; tile_hdr[j] = (1u << 28) + ((uint32_t)pr << 24) + (uint32_t)fsz; }  // libxpng.c:563-564
-    else { tile_sz[j] = (uint32_t)raw; tile_hdr[j] = (uint32_t)raw; }                                                  // libxpng.c:566
+    const uint32_t il = imglin(sel, tile);  // sizes are scanned per image, in tile order
+    if (fsz < raw) { tile_sz[il] = (uint32_t)fsz; tile_hdr[il] = (1u << 28) + ((uint32_t)pr << 24) + (uint32_t)fsz; }  // libxpng.c:563-564
+    else { tile_sz[il] = (uint32_t)raw; tile_hdr[il] = (uint32_t)raw; }                                                  // libxpng.c:566
 }
 
 // K5b  exclusive scan of tile sizes -> byte offsets inside each image's blob buffer.  One workgroup per image:
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256) void k_tile_gather(const uint8_t *const *__res
     const uint32_t j = blockIdx.x, tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
     const uint8_t *__restrict__ raster = rasters[t.img];
-    uint8_t *dst = blobs[t.img] + off[(uint64_t)(j / sel.cnt) * (sel.cnt + 1) + j % sel.cnt];
-    const uint32_t hdr = tile_hdr[j];
+    const uint32_t il = imglin(sel, tile);
+    uint8_t *dst = blobs[t.img] + off[(uint64_t)il + il / sel.cnt];  // off holds cnt + 1 entries per image
+    const uint32_t hdr = tile_hdr[il];
     if (threadIdx.x < 4) dst[threadIdx.x] = (uint8_t)(hdr >> (8 * threadIdx.x));
     if ((hdr >> 24) == 0) {  // raw tile: rows (libxpng.c:566-567)
         const uint64_t row = (uint64_t)t.w * pxsz;

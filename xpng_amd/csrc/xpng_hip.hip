@@ -98,6 +98,7 @@ struct xpnghip_ctx {
     std::vector<void *> h_out_ptrs;
     // decode keeps its own pair of tables: a caller that alternates encode and decode on one context (a pipeline) would
     // otherwise re-upload, and synchronise its stream, on every call
+    uint32_t *d_order = nullptr;          // tile indices of [r0, r1) by decreasing pixel count (TileSel::order)
     hipStream_t enc_side = nullptr;       // the alpha chains of a batched encode run beside the context chains
     hipEvent_t ev_enc_fork = nullptr, ev_enc_join = nullptr;
     const uint8_t **d_dec_in_ptrs = nullptr;
@@ -128,7 +129,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
-                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs,
+                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
                     c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
@@ -190,7 +191,14 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
     ALLOC(c->d_out_ptrs, (uint64_t)batch * 8);
     ALLOC(c->d_dec_in_ptrs, (uint64_t)batch * 8);
     ALLOC(c->d_dec_out_ptrs, (uint64_t)batch * 8);
+    ALLOC(c->d_order, (c->r1 - c->r0) * 4);
 #undef ALLOC
+    {   // tiles of [r0, r1) by decreasing pixel count (stable: equal sizes stay in tile order)
+        std::vector<uint32_t> ord;
+        for (uint64_t i = c->r0; i < c->r1; i++) ord.push_back((uint32_t)i);
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return c->tiles[a].n > c->tiles[b].n; });
+        if (hipMemcpy(c->d_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { xpnghip_ctx_destroy(c); return fail("context setup failed"); }
+    }
     c->stamps = getenv("XPNG_STAMPS") != nullptr;
     if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipMemcpy(c->d_tiles, all.data(), VN * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess) {
@@ -246,11 +254,16 @@ static int set_ptrs(xpnghip_ctx *c, const void *const *in, void *const *outp, ui
     return 0;
 }
 
+// the tile-major, size-sorted enumeration applies to launches over the context's whole tile range (XPNG_IMAGE_MAJOR=1: off)
+static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1) {
+    return (t0 == c->r0 && t1 == c->r1 && !getenv("XPNG_IMAGE_MAJOR")) ? c->d_order : nullptr;
+}
+
 // chooser + transform (BASELINE config 2).  Launch only; no sync.  d_in_ptrs already holds the raster pointers.
 template <int PXSZ>
 static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
-    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
@@ -292,7 +305,7 @@ extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *con
 template <int PXSZ>
 static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
-    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
     if ((uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
@@ -348,7 +361,7 @@ static int ensure_m2(xpnghip_ctx *c) {
 static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
     if (ensure_m2(c)) return 1;
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
-    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size()};
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};
     const uint64_t bpr = c->W * 3, VN = (uint64_t)c->B * sel.N;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
@@ -420,7 +433,8 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
                                 (uint32_t)t1, c->d_dec_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
     }
     return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off,
-                            (uint32_t)t0, (uint32_t)t1, c->d_dec_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr);
+                            (uint32_t)t0, (uint32_t)t1, c->d_dec_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr,
+                            order_for(c, (uint32_t)t0, (uint32_t)t1));
 }
 extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
                                      const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
