@@ -284,6 +284,17 @@ def main():
     achieved = algo_bytes / (tr_ms * 1e-3) / 1e9
 
     if rank == 0:
+        # HBM bytes per launch of the roofline kernels from the committed PMC passes (FETCH_SIZE doubled + WRITE_SIZE, per pixel):
+        # counters cannot be collected inside this run, so the figure is the profile's bytes/px times this launch's pixels
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_transform.json")
+        if alpha and args.kind == "photo" and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                traffic = int(pmc["per_pixel_bytes"]["total"] * B * my_px)
+                traffic_src = "profiles/r01_pmc_transform.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/px of that run x pixels of this launch)"
+            except Exception:
+                traffic, traffic_src = None, None
         out = {
             "metric": "Mpixels/s encode+decode (bit-exact vs ref)",
             "value": round(B * total_px * args.steps / elapsed / 1e6, 1),
@@ -301,7 +312,7 @@ def main():
             "single_image_encode_ms": round(enc_ms, 3), "single_image_decode_ms": round(dec_ms, 3),
             "roofline": {"kernel": "k_chooser + k_m1_transform (predictor chooser + per-pixel transform, BASELINE config 2)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_px": ALGO_BYTES_PER_PX[ch], "ms_per_launch": round(tr_ms, 4),
                          "transform_mpx_s": round(B * my_px / tr_ms / 1e3, 1), "images_per_launch": B,
                          "read_only_frac_of_peak": round(ch * B * my_px / (tr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
