@@ -158,9 +158,13 @@ def main():
     assert ctx.tiles() == tiles
     y0, y1 = band_rows(tiles, t0, t1)
     # the rank materialises only the raster band its tiles touch (+ one spare row: the staged 16-byte loads of the last
-    # row may run a few bytes past it when the band is not the tail of the image)
-    band_store = synth_raster_torch(args.kind, W, min(H, y1 + 1) - y0, alpha, y0=y0, device=f"cuda:{local_rank}")
-    band = band_store[: y1 - y0]
+    # row may run a few bytes past it when the band is not the tail of the image).  The B rasters of a launch are DISTINCT
+    # (seeds 1..B; image 0 is the one the manifest pins): identical rasters would sit in the 256 MB Infinity Cache for the
+    # roofline kernels and would make every lane of the wide entropy kernels take the same branches.
+    dev = f"cuda:{local_rank}"
+    band_stores = [synth_raster_torch(args.kind, W, min(H, y1 + 1) - y0, alpha, seed=1 + b, y0=y0, device=dev) for b in range(B)]
+    bands = [bs[: y1 - y0] for bs in band_stores]
+    band = bands[0]
     bpr = W * ch
     d_raster_virtual = band.data_ptr() - y0 * bpr  # kernels address rows absolutely; only [y0, y1) is ever touched
     d_blobs_all = [torch.empty(ctx.blob_bound(t0, t1) + 64, dtype=torch.uint8, device=band.device) for _ in range(B)]
@@ -168,7 +172,7 @@ def main():
     d_blobs, d_back = d_blobs_all[0], d_back_all[0]
     d_back_virtual = d_back.data_ptr() - y0 * bpr
     stream = torch.cuda.current_stream().cuda_stream
-    rast_ptrs = [d_raster_virtual] * B  # the same synthetic raster, encoded B times into B separate outputs
+    rast_ptrs = [bd.data_ptr() - y0 * bpr for bd in bands]
     blob_ptrs = [t.data_ptr() for t in d_blobs_all]
     back_ptrs = [t.data_ptr() - y0 * bpr for t in d_back_all]
     # pipeline slots: slot 0 is (ctx, current stream, the buffers above); further slots get their own context / stream / buffers
@@ -183,34 +187,42 @@ def main():
     my_px = sum(t[2] * t[3] for t in tiles[t0:t1])
     total_px = W * H
 
-    # ---- correctness gate (untimed): bit-exact vs reference manifest where pinned, round trip always
+    def same_tiles(a, b):  # rows shared with a neighbouring rank's tiles are not written by this rank: compare tile by tile
+        if world == 1:
+            return bool(torch.equal(a, b))
+        return all(bool(torch.equal(a[ty - y0:ty - y0 + th, tx:tx + tw], b[ty - y0:ty - y0 + th, tx:tx + tw])) for (tx, ty, tw, th) in tiles[t0:t1])
+
+    # ---- correctness gate (untimed): bit-exact vs reference manifest where pinned (image 0), round trip for every image
     n = ctx.encode_device(1, d_raster_virtual, d_blobs.data_ptr(), t0, t1, stream=stream)
-    blobs_local = d_blobs[:n]
-    off, tot = walk_tile_offsets(blobs_local.cpu().numpy().tobytes(), t1 - t0)
-    assert tot == n
-    ctx.decode_device(1, d_blobs.data_ptr(), n, off, d_back_virtual, t0, t1, stream=stream)
+    blob0 = d_blobs[:n].clone()
+    lens_b = ctx.encode_device_batch(1, rast_ptrs, blob_ptrs, t0, t1, stream=stream)   # all B images, one launch sequence
+    ok = lens_b[0] == n and bool(torch.equal(d_blobs_all[0][:n], blob0))                # batched == single-image launch
+    offs_b = []
+    for bi in range(B):
+        o, tot = walk_tile_offsets(d_blobs_all[bi][:lens_b[bi]].cpu().numpy().tobytes(), t1 - t0)
+        ok = ok and tot == lens_b[bi]
+        offs_b.append(o)
+    off = offs_b[0]
+    ctx.decode_device_batch(1, blob_ptrs, lens_b, offs_b, back_ptrs, t0, t1, stream=stream)
     torch.cuda.synchronize()
-    # rows shared with a neighbouring rank's tiles are not written by this rank: compare tile by tile
-    ok = True
-    for (tx, ty, tw, th) in tiles[t0:t1]:
-        ok = ok and torch.equal(d_back[ty - y0:ty - y0 + th, tx:tx + tw], band[ty - y0:ty - y0 + th, tx:tx + tw])
-    verified = {"roundtrip": bool(ok)}
+    ok = ok and ctx.decode_status() == 0
+    for bi in range(B):
+        ok = ok and same_tiles(d_back_all[bi], bands[bi])
+    verified = {"roundtrip": bool(ok), "images_verified": B}
     use_host = world > 1 and args.backend != "nccl"
 
     def exchange(bufs=None):  # the one exchange of the path: every rank's B blobs -> rank 0 (RCCL send/recv; no collective on the data path)
         bufs = d_blobs_all if bufs is None else bufs
         if not use_host:
-            return gather_blobs_batch(bufs, [n] * B)
-        outs, table = gather_blobs_batch([t[:n].cpu() for t in bufs], [n] * B)
+            return gather_blobs_batch(bufs, lens_b)
+        outs, table = gather_blobs_batch([t[:lens_b[i]].cpu() for i, t in enumerate(bufs)], lens_b)
         return outs, table
 
     if world > 1:
-        for bi in range(1, B):
-            d_blobs_all[bi][:n].copy_(d_blobs_all[0][:n])  # (only image 0 has been encoded so far)
         outs, table = exchange()
         gathered, lens = (outs[0] if rank == 0 else None), [row[0] for row in table]
     else:
-        gathered, lens = blobs_local, [n]
+        gathered, lens = d_blobs_all[0][:n], [n]
     if rank == 0:
         man_path = os.path.join(ROOT, "tests", "golden", "manifest.json")
         key = f"synth_{args.kind}_{W}x{H}_{'rgba' if alpha else 'rgb'}"
@@ -223,6 +235,7 @@ def main():
                 ok = ok and verified["reference_md5"]
     if not ok:
         raise SystemExit(f"rank {rank}: output is NOT bit-exact / does not round-trip: {verified}")
+    ref_blobs = [d_blobs_all[bi][:lens_b[bi]].clone() for bi in range(B)]  # what every slot must reproduce
 
     def step():
         # one launch sequence covers all B images (virtual tile = image * N + tile); consecutive steps alternate pipeline slots
@@ -232,8 +245,8 @@ def main():
         sl["ctx"].encode_device_batch(1, rast_ptrs, sl["blob_ptrs"], t0, t1, stream=sh, sync=False)
         if world > 1:
             with torch.cuda.stream(sl["stream"]):
-                exchange(sl["blobs"])  # tile bytes are deterministic: n is the length verified above
-        sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], [n] * B, [off] * B, sl["back_ptrs"], t0, t1, stream=sh)
+                exchange(sl["blobs"])  # tile bytes are deterministic: the lengths are the ones verified above
+        sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], lens_b, offs_b, sl["back_ptrs"], t0, t1, stream=sh)
 
     def barrier():
         torch.cuda.synchronize()
@@ -263,7 +276,7 @@ def main():
     # every image of every pipeline slot must have produced the verified bytes and raster
     for si, sl in enumerate(slots):
         for bi in range(B):
-            if ctx_len_at(sl["ctx"], bi) != n or not torch.equal(sl["blobs"][bi][:n], d_blobs_all[0][:n]) or not torch.equal(sl["back"][bi], d_back_all[0]):
+            if ctx_len_at(sl["ctx"], bi) != lens_b[bi] or not torch.equal(sl["blobs"][bi][:lens_b[bi]], ref_blobs[bi]) or not same_tiles(sl["back"][bi], bands[bi]):
                 raise SystemExit(f"rank {rank}: slot {si} image {bi} differs from the verified image")
 
     # ---- per-stage rates on this rank (HIP events on the stream the kernels run on)
@@ -306,7 +319,7 @@ def main():
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' {'RGBA8' if alpha else 'RGB8'}, level -1 (FAST), tile encode + decode, rasters and blobs resident in HBM",
                        "batch": B, "pipeline_slots": P, "tiles": len(tiles), "tiles_per_rank": t1 - t0, "share_px": my_px,
                        "parallelism": f"tile-range x{world}" + (f" + gatherv of blobs to rank 0 ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
-                       "compressed_bytes": int(sum(lens))},
+                       "compressed_bytes": int(sum(lens)), "distinct_rasters_per_launch": B},
             "verified": verified,
             "single_image_encode_mpx_s": round(my_px / enc_ms / 1e3, 1), "single_image_decode_mpx_s": round(my_px / dec_ms / 1e3, 1),
             "single_image_encode_ms": round(enc_ms, 3), "single_image_decode_ms": round(dec_ms, 3),

@@ -263,7 +263,9 @@ static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1)
 template <int PXSZ>
 static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
-    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
+    // image-major here: these two kernels stream the rasters, and neighbouring workgroups on neighbouring rows of ONE raster
+    // keep HBM pages open (measured with 64 distinct rasters: 2.25 ms per launch against 2.4-2.6 tile-major)
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
