@@ -301,9 +301,13 @@ __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const Tile
 __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                            uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
                                                            uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
-                                                           uint8_t *__restrict__ planes, uint64_t plane_stride) {
+                                                           uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks) {
     __shared__ __align__(16) uint8_t rows[(TR_ROWS + 1) * TR_PITCH];
-    const uint32_t tile = vtile(sel, blockIdx.x / strips_per_tile), strip = blockIdx.x % strips_per_tile;
+    // Consecutive block ids round-robin over the 8 XCDs, each with its own L2; consecutive strips of a tile share a halo row.
+    // The grid is padded to a multiple of 8 and re-read so that each XCD works through a contiguous run of strips.
+    const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (bid >= nblocks) return;
+    const uint32_t tile = vtile(sel, bid / strips_per_tile), strip = bid % strips_per_tile;
     const TileDesc t = tiles[tile];
     const uint32_t y0 = strip * TR_ROWS;
     if (y0 >= t.h) return;
