@@ -16,10 +16,13 @@ $(LIB)/libxpng_hip.so: $(HIPSRC) $(HIPHDR)
 	@mkdir -p $(LIB)
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -shared -fPIC -Wall -Wno-unused-function $(HIPSRC) -o $@
 
-host: $(LIB)/libxpng.so $(BIN)/xpng $(BIN)/seven
+host: $(LIB)/libxpng.so $(BIN)/xpng $(BIN)/seven $(BIN)/tool
 $(LIB)/libxpng.so: $(CSRC)/host/xpng_api.c $(CSRC)/host/seven.c include/xpng.h include/xpng_hip.h $(LIB)/libxpng_hip.so
 	$(CC) -O2 -std=gnu11 -Wall -Wextra -shared -fPIC $(CSRC)/host/xpng_api.c $(CSRC)/host/seven.c -o $@ \
 	    -L$(LIB) -lxpng_hip -Wl,-rpath,'$$ORIGIN'
+$(BIN)/tool: $(CSRC)/host/tool_cli.c $(LIB)/libxpng.so
+	@mkdir -p $(BIN)
+	$(CC) -O2 -std=gnu11 -Wall -Wextra $(CSRC)/host/tool_cli.c -o $@ -L$(LIB) -lxpng -lxpng_hip -Wl,-rpath,'$$ORIGIN/../lib'
 $(BIN)/seven: $(CSRC)/host/seven_cli.c $(LIB)/libxpng.so
 	@mkdir -p $(BIN)
 	$(CC) -O2 -std=gnu11 -Wall -Wextra $(CSRC)/host/seven_cli.c -o $@ -L$(LIB) -lxpng -lxpng_hip -ldl -Wl,-rpath,'$$ORIGIN/../lib'

@@ -372,3 +372,30 @@ def test_normalize_rgba_on_device_matches_oracle(gpu, po):
         got = d_out[: w * h * pxsz].cpu().numpy().reshape(h, w, pxsz) if rewritten else r
         assert np.array_equal(got, want), case
         assert rewritten == (case != "translucent"), case
+
+
+def test_orientation_search_sizes_match_oracle(gpu, po, tmp_path, monkeypatch, capsys):
+    """tools/orient_search.py (the reference's Mirroring_and_Rotating/test.rb on the GPU: 8 orientations, batched per
+    geometry): every listed size equals what the oracle's encode_image gives for that orientation."""
+    import importlib.util
+    import sys
+    from xpng_amd.synth import synth_raster, to_seven_bytes
+    spec = importlib.util.spec_from_file_location("orient_search", os.path.join(os.path.dirname(GOLD), "..", "tools", "orient_search.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for alpha in (False, True):
+        r = synth_raster("photo", 610, 470, alpha)
+        p = tmp_path / "o.7"
+        p.write_bytes(to_seven_bytes(r))
+        monkeypatch.setattr(sys, "argv", ["orient_search.py", str(p), "2"])
+        sizes = mod.main()
+        assert len(sizes) == 8
+        want = {}
+        cur = r
+        for rot in ("   0", "  90", " 180", " 270"):
+            ms = ("    ", " + v", " + h") if rot in ("   0", "  90") else ("    ",)
+            for m in ms:
+                v = cur if m == "    " else (cur[::-1] if m == " + v" else cur[:, ::-1])
+                want[rot + m] = len(po.encode_image(2, np.ascontiguousarray(v)))
+            cur = np.rot90(cur, k=-1)
+        assert sizes == want
