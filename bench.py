@@ -98,8 +98,8 @@ def ctx_len_at(ctx, i):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--image", type=int, default=0, help="fix the GLOBAL raster at image x image pixels (strong scaling)")
     ap.add_argument("--share", type=int, default=4096, help="per-rank share edge in pixels (weak scaling)")
     ap.add_argument("--rgb", action="store_true", help="RGB instead of RGBA")
@@ -248,6 +248,20 @@ def main():
                 exchange(sl["blobs"])  # tile bytes are deterministic: the lengths are the ones verified above
         sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], lens_b, offs_b, sl["back_ptrs"], t0, t1, stream=sh)
 
+    # ---- per-stage rates on this rank (HIP events on the stream the kernels run on)
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps  # ms
+
+    # the roofline kernels run over the whole batch per launch (a single 4096^2 pass is ~30 us, i.e. launch-bound); timed
+    # here, before the pipelined steps, with nothing else on the device
+    tr_ms = timed(lambda: ctx.transform_device_batch(rast_ptrs, t0, t1, stream=stream), args.roofline_reps)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -279,20 +293,8 @@ def main():
             if ctx_len_at(sl["ctx"], bi) != lens_b[bi] or not torch.equal(sl["blobs"][bi][:lens_b[bi]], ref_blobs[bi]) or not same_tiles(sl["back"][bi], bands[bi]):
                 raise SystemExit(f"rank {rank}: slot {si} image {bi} differs from the verified image")
 
-    # ---- per-stage rates on this rank (HIP events on the stream the kernels run on)
-    def timed(fn, reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn(); torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps  # ms
-
     enc_ms = timed(lambda: ctx.encode_device(1, d_raster_virtual, d_blobs.data_ptr(), t0, t1, stream=stream, sync=False), max(3, args.steps // 2))
     dec_ms = timed(lambda: ctx.decode_device(1, d_blobs.data_ptr(), n, off, d_back_virtual, t0, t1, stream=stream), max(3, args.steps // 2))
-    # the roofline kernels run over the whole batch per launch (a single 4096^2 pass is ~30 us, i.e. launch-bound)
-    tr_ms = timed(lambda: ctx.transform_device_batch(rast_ptrs, t0, t1, stream=stream), args.roofline_reps)
     algo_bytes = ALGO_BYTES_PER_PX[ch] * my_px * B
     achieved = algo_bytes / (tr_ms * 1e-3) / 1e9
 

@@ -14,16 +14,26 @@ for r in rows:
     if "xpng" in r["Kernel_Name"]: per[(name(r), wg(r))].append(dur(r))
 kern = [{"kernel": k, "workgroups": g, "launches": len(v), "total_ms": round(sum(v), 3), "avg_ms": round(sum(v) / len(v), 4),
          "min_ms": round(min(v), 4), "max_ms": round(max(v), 4)} for (k, g), v in sorted(per.items(), key=lambda x: -sum(x[1]))]
-reps = 50
+# the roofline measurement = the longest run of consecutive chooser / transform launches on the batched grid with no other
+# kernel of the library in between (the pipelined steps interleave other kernels)
+xp = [r for r in rows if "xpng" in r["Kernel_Name"]]
+def is_roof(r): return name(r).startswith(("k_chooser", "k_m1_transform"))
+best, cur = [], []
+for r in xp:
+    if is_roof(r): cur.append(r)
+    else:
+        if len(cur) > len(best): best = cur
+        cur = []
+if len(cur) > len(best): best = cur
 roof = {}
 for key in ("k_chooser", "k_m1_transform"):
-    cands = [(k, g) for (k, g) in per if k.startswith(key)]
-    if not cands: continue
-    k, g = max(cands, key=lambda x: x[1])  # the batched grid
-    v = per[(k, g)]
-    iso = v[-reps:]
+    iso = [dur(r) for r in best if name(r).startswith(key)]
+    if not iso: continue
+    k, g = next((name(r), wg(r)) for r in best if name(r).startswith(key))
+    allv = per[(k, g)]
+    rest = len(allv) - len(iso)
     roof[k] = {"workgroups": g, "isolated_launches": len(iso), "isolated_avg_ms": round(sum(iso) / len(iso), 4),
-               "in_pipeline_launches": len(v) - len(iso), "in_pipeline_avg_ms": round(sum(v[:-reps]) / max(1, len(v) - len(iso)), 4)}
+               "in_pipeline_launches": rest, "in_pipeline_avg_ms": round((sum(allv) - sum(iso)) / max(1, rest), 4)}
 tot = sum(x["isolated_avg_ms"] for x in roof.values())
 print(json.dumps({"bench_line": benchj, "roofline_kernels": roof, "roofline_isolated_sum_ms": round(tot, 4),
                   "bench_ms_per_launch": benchj["roofline"]["ms_per_launch"], "kernels": kern}, indent=1))
