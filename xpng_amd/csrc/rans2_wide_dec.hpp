@@ -38,6 +38,7 @@ struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_p
 //                   by the reference encoder) is left to the one-wave-per-stream kernel
 template <bool BIG> struct WdLayout {
     static constexpr uint32_t CBITS = BIG ? 10 : 8, FCN = BIG ? 256 : 16, RING = BIG ? 64 : 32;
+    static constexpr uint32_t REGN = 9;  // small layout: at most 9 symbols (nl = 0..8), searched in registers
     static constexpr uint32_t CO_OFF = 4 * (FCN + 1), TAB = CO_OFF + (1u << CBITS);
 };
 constexpr uint32_t WD_TAB_MAX = WdLayout<true>::TAB;  // HBM stride of one stream's tables
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
     }
     __syncthreads();
     uint8_t *gt = dtab + ((uint64_t)j * 10 + c) * WD_TAB_MAX;
-    const bool small = c < 9 && pb <= 12 && N <= WdLayout<false>::FCN;
+    const bool small = c < 9 && pb <= 12 && N <= WdLayout<false>::REGN;
     const uint32_t fcn = small ? WdLayout<false>::FCN : WdLayout<true>::FCN, co_off = 4 * (fcn + 1);
     const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayout<true>::CBITS;
     uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
@@ -258,6 +259,15 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         const uint32_t e0 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs0), e1 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs1);
         hF0 = e0 & 0xFFFFu; hC0 = e0 >> 16; hF1 = e1 & 0xFFFFu; hC1 = e1 >> 16;
     }
+    // Small layout (nl-context streams, at most 9 symbols): the cumulative counts c1..c9 live in registers and a step finds
+    // its symbol with 9 compares and max / min folds: ~50 VALU instructions, the same for every lane, instead of two
+    // dependent LDS reads and a data-dependent scan that the whole wave waits for.  (c_i = 2^pb for i >= N.)
+    uint32_t cm[10];
+#pragma unroll
+    for (int i = 1; i <= 9; i++) {
+        cm[i] = 1u << pb;
+        if (!BIG && live && (uint32_t)i < wd->N) cm[i] = *(const lds32 *)(uintptr_t)(a_fc + 4 * i) >> 16;
+    }
     // one symbol out of this lane's state, the pair's renormalisation (state1 refills first, libxpng.c:486-487)
     auto step = [&](bool act, uint32_t obpos) __attribute__((always_inline)) -> uint32_t {
         const uint32_t slot = slo & mask;
@@ -266,6 +276,18 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         const bool h0 = d0 < hF0, h1 = d1 < hF1;
         if (HOT && __ballot(!(h0 || h1)) == 0) {
             sym = h0 ? hs0 : hs1; F = h0 ? hF0 : hF1; off = h0 ? d0 : d1;
+        } else if (!BIG) {
+            sym = 0;
+            uint32_t cum = 0, nxt = 1u << pb;
+#pragma unroll
+            for (int i = 1; i <= 9; i++) {
+                const bool ge = slot >= cm[i];
+                sym += ge ? 1u : 0u;
+                const uint32_t lo_c = ge ? cm[i] : 0u, hi_c = ge ? (1u << 16) : cm[i];
+                cum = lo_c > cum ? lo_c : cum;
+                nxt = hi_c < nxt ? hi_c : nxt;
+            }
+            F = nxt - cum; off = slot - cum;
         } else {
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
             uint32_t e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym);
