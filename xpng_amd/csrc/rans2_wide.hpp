@@ -24,7 +24,9 @@ struct WPrep {
 };
 __device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 + c * 256 : 0; }
 
-__global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
+// streams [c_first, c_first + c_count) of every tile (the alpha streams, c = 9, are prepared and chained while the stream-
+// formation kernel is still producing the context streams: they only need the transform's alpha plane)
+__global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first, uint32_t c_count,
                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                    uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
-    const uint32_t tile = vtile(sel, blockIdx.x / spt), c = blockIdx.x % spt, lane = threadIdx.x & 63;
+    const uint32_t tile = vtile(sel, blockIdx.x / c_count), c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63;
     const TileDesc t = tiles[tile];
     uint8_t *sc = scratch + t.sbase;
     const uint8_t *in;

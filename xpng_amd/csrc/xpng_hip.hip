@@ -310,29 +310,31 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
+    const bool narrow = getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"));
+    // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the transform's alpha plane,
+    // so their preparation and the chains themselves start here, on their own stream, beside stream formation.
+    const bool alpha_early = !narrow && PXSZ == 4;
+    if (alpha_early) {
+        if (!c->enc_side) {
+            HIPCHK(hipStreamCreateWithFlags(&c->enc_side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(c->ev_enc_fork, s));
+        HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
+        k_rans2_prep<<<total, 64, 0, c->enc_side>>>(c->d_tiles, sel, 9, 1, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
+        k_rans2_chain2<true><<<(total + 15) / 16, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        HIPCHK(hipEventRecord(c->ev_enc_join, c->enc_side));
+    }
     if ((uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    if (getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"))) {
+    if (narrow) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        k_rans2_prep<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        {
-            // the alpha chains are the longest: they run on their own stream beside the context chains
-            if (PXSZ == 4) {
-                if (!c->enc_side) {
-                    HIPCHK(hipStreamCreateWithFlags(&c->enc_side, hipStreamNonBlocking));
-                    HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
-                    HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
-                }
-                HIPCHK(hipEventRecord(c->ev_enc_fork, s));
-                HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
-                k_rans2_chain2<true><<<(total + 15) / 16, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
-                HIPCHK(hipEventRecord(c->ev_enc_join, c->enc_side));
-            }
-            k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
-            if (PXSZ == 4) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
-        }
+        k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
+        k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        if (alpha_early) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
         k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
