@@ -177,7 +177,8 @@ def main():
     back_ptrs = [t.data_ptr() - y0 * bpr for t in d_back_all]
     # pipeline slots: slot 0 is (ctx, current stream, the buffers above); further slots get their own context / stream / buffers
     P = max(1, args.pipeline)
-    slots = [dict(ctx=ctx, stream=torch.cuda.current_stream(), blobs=d_blobs_all, back=d_back_all, blob_ptrs=blob_ptrs, back_ptrs=back_ptrs)]
+    # (slot 0 gets a stream of its own for the steps as well: the default stream is the legacy NULL stream)
+    slots = [dict(ctx=ctx, stream=torch.cuda.Stream(), blobs=d_blobs_all, back=d_back_all, blob_ptrs=blob_ptrs, back_ptrs=back_ptrs)]
     for _ in range(P - 1):
         bl = [torch.empty_like(d_blobs_all[0]) for _ in range(B)]
         bk = [torch.zeros_like(band) for _ in range(B)]
