@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
                                                       uint8_t *__restrict__ nlseq) {
     __shared__ u32x4_t head[10 * 64];
-    constexpr uint32_t WCH = 8, SVC = 4, WDW = WCH * 4;  // window: 8 chunks of 16 B = 32 dwords per queue; a queue is serviced every 4th block
+    constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;  // window: 8 chunks of 16 B = 32 dwords per queue; a queue is serviced every 4th block
     __shared__ uint32_t ringw[10 * WDW * 64];
     __builtin_amdgcn_s_setprio(3);
  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
