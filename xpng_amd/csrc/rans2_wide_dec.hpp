@@ -260,8 +260,8 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         hF0 = e0 & 0xFFFFu; hC0 = e0 >> 16; hF1 = e1 & 0xFFFFu; hC1 = e1 >> 16;
     }
     // Small layout (nl-context streams, at most 9 symbols): the cumulative counts c1..c9 live in registers and a step finds
-    // its symbol with 9 compares and max / min folds: ~50 VALU instructions, the same for every lane, instead of two
-    // dependent LDS reads and a data-dependent scan that the whole wave waits for.  (c_i = 2^pb for i >= N.)
+    // its symbol by a binary search over them, instead of two dependent LDS reads and a data-dependent scan that the whole
+    // wave waits for.  (c_i = 2^pb for i >= N.)
     uint32_t cm[10];
 #pragma unroll
     for (int i = 1; i <= 9; i++) {
@@ -277,16 +277,20 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         if (HOT && __ballot(!(h0 || h1)) == 0) {
             sym = h0 ? hs0 : hs1; F = h0 ? hF0 : hF1; off = h0 ? d0 : d1;
         } else if (!BIG) {
-            sym = 0;
-            uint32_t cum = 0, nxt = 1u << pb;
-#pragma unroll
-            for (int i = 1; i <= 9; i++) {
-                const bool ge = slot >= cm[i];
-                sym += ge ? 1u : 0u;
-                const uint32_t lo_c = ge ? cm[i] : 0u, hi_c = ge ? (1u << 16) : cm[i];
-                cum = lo_c > cum ? lo_c : cum;
-                nxt = hi_c < nxt ? hi_c : nxt;
-            }
+            // binary search over c1..c8 in registers (three compares, a fourth for symbol 8), then [cum, next) by the same
+            // decisions: ~30 VALU instructions, the same for every lane, no LDS
+            const bool b2 = slot >= cm[4];
+            const bool b1 = slot >= (b2 ? cm[6] : cm[2]);
+            const uint32_t t3 = b2 ? (b1 ? cm[7] : cm[5]) : (b1 ? cm[3] : cm[1]);
+            const bool b0 = slot >= t3;
+            const bool b3 = b2 && b1 && b0 && slot >= cm[8];
+            sym = (b2 ? 4u : 0u) + (b1 ? 2u : 0u) + (b0 ? 1u : 0u) + (b3 ? 1u : 0u);
+            // cum = c[sym], next = c[sym + 1] (c0 = 0)
+            const uint32_t lo01 = b0 ? cm[1] : 0u, lo23 = b0 ? cm[3] : cm[2], lo45 = b0 ? cm[5] : cm[4], lo67 = b0 ? cm[7] : cm[6];
+            const uint32_t hi01 = b0 ? cm[2] : cm[1], hi23 = b0 ? cm[4] : cm[3], hi45 = b0 ? cm[6] : cm[5], hi67 = b0 ? cm[8] : cm[7];
+            const uint32_t lo03 = b1 ? lo23 : lo01, lo47 = b1 ? lo67 : lo45, hi03 = b1 ? hi23 : hi01, hi47 = b1 ? hi67 : hi45;
+            uint32_t cum = b2 ? lo47 : lo03, nxt = b2 ? hi47 : hi03;
+            cum = b3 ? cm[8] : cum; nxt = b3 ? cm[9] : nxt;
             F = nxt - cum; off = slot - cum;
         } else {
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
