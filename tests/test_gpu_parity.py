@@ -399,3 +399,31 @@ def test_orientation_search_sizes_match_oracle(gpu, po, tmp_path, monkeypatch, c
                 want[rot + m] = len(po.encode_image(2, np.ascontiguousarray(v)))
             cur = np.rot90(cur, k=-1)
         assert sizes == want
+
+
+@pytest.mark.parametrize("force_wide", [False, True])
+def test_extreme_aspect_ratios(gpu, po, monkeypatch, force_wide):
+    """Tiles far from 444 x 444 (libxpng.c:51-83 keeps w*h near 444^2: a 4-pixel-high raster gets tiles ~49 000 px wide, beyond
+    the LDS-staged transform and the band reconstruction, so the generic kernels are used): encode == oracle, decode round-trips,
+    on the narrow and on the wide entropy path."""
+    import torch
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import synth_raster
+    if force_wide:
+        monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    for (w, h, a) in [(30000, 4, True), (4, 30000, True), (50000, 5, False), (7, 9000, False), (100000, 4, True)]:
+        r = synth_raster("photo", w, h, a)
+        ch = r.shape[2]
+        ctx = gpu.Context(w, h, ch)
+        d_r = torch.from_numpy(r).cuda()
+        d_b = torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        n = ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
+        blob = d_b[:n].cpu().numpy().tobytes()
+        assert blob == po.encode_tiles(1, r), (w, h, a)
+        off, _ = walk_tile_offsets(blob, ctx.n_tiles)
+        d_o = torch.zeros(w * h * ch + 64, dtype=torch.uint8, device="cuda")
+        ctx.decode_device(1, d_b.data_ptr(), n, off, d_o.data_ptr())
+        torch.cuda.synchronize()
+        assert ctx.decode_status() == 0
+        assert np.array_equal(d_o[: w * h * ch].cpu().numpy().reshape(h, w, ch), r), (w, h, a)
+        ctx.close()
