@@ -497,16 +497,17 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 // previous step (advance the position, pull the next window dword, write the head back) is issued behind that read and
 // completes while it is in flight; when the same queue is popped twice in a row the read is stale and the registers of
 // the previous step are forwarded instead.  Queue 9 is a parking queue that returns 9 forever: a lane whose tile is
-// finished walks it.  Global memory is touched only every 16 steps: one aligned 16-byte chunk per queue is requested at
-// a boundary and lands in the window at the next one (the chunk starts are 16-byte aligned, k_dec_parse).
+// finished walks it.  Global memory is touched only at 16-step block boundaries: aligned 16-byte chunks are requested for a
+// queue at one service and land in its window at the next (the chunk starts are 16-byte aligned, k_dec_parse).
 __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
                                                       uint8_t *__restrict__ nlseq) {
     __shared__ u32x4_t head[10 * 64];
-    constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;  // window: 8 chunks of 16 B = 32 dwords per queue; a queue is serviced every 4th block
+    // window: WCH chunks of 16 B per queue; a queue is serviced every SVC-th block.  (8 chunks / every 4th block is ~8 % faster
+    // alone, but 90 KB of LDS per wave instead of 50 costs the kernels beside it more than that.)
+    constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;
     __shared__ uint32_t ringw[10 * WDW * 64];
-    __builtin_amdgcn_s_setprio(3);
- // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 64 + lane;
     bool live = j < total_tiles;
     const DecTile *d = info + (live ? j : 0);
@@ -566,8 +567,8 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
         }
         if (kb < total) *reinterpret_cast<uint4 *>(out + kb) = make_uint4(o[0], o[1], o[2], o[3]);
     };
-    // Service of the queues of one phase, every SVC-th block boundary (so a request has 64 steps, not 16, to come back: 64
-    // lanes x 9 queues are 576 different cache lines per round, and a round asks for whole 64-byte lines).  Up to SVC
+    // Service of the queues of one phase, every SVC-th block boundary (so a request has 16 * SVC steps, not 16, to come back:
+    // 64 lanes x 9 queues are 576 different cache lines per round).  Up to SVC
     // chunks land while their window slots have been read out; after a service the window holds >= 16 * SVC unread bytes
     // (SVC blocks' worth) or everything up to its capacity; the next SVC missing chunks are requested again either way.
     // (The head of queue pcur in LDS is one pop behind the registers; a chunk index can only be underestimated by that.)
