@@ -20,6 +20,7 @@
 #include "m2_encode.hpp"
 #include "rans2.hpp"
 #include "rans2_wide.hpp"
+#include "rans1_wide.hpp"
 #include "tile_container.hpp"
 
 using namespace xpng;
@@ -116,6 +117,9 @@ struct xpnghip_ctx {
     M2Tile *d_mt2 = nullptr;
     M2DecTile *d_info2 = nullptr;
     uint16_t *d_tabs2 = nullptr;
+    W1Prep *d_w1prep = nullptr;           // wide rANS v1 encode (rans1_wide.hpp): descriptors, encoder tables, frequencies
+    uint8_t *d_w1tab = nullptr;
+    uint16_t *d_w1F = nullptr;
     int stamps = 0;  // XPNG_STAMPS=1: chain kernels record s_memtime phase stamps (debug_fetch 40/41)
     uint64_t *h_total = nullptr;  // pinned, B entries
     hipStream_t stream = nullptr;
@@ -130,7 +134,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
-                    c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2};
+                    c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
     if (c->ev_enc_fork) (void)hipEventDestroy(c->ev_enc_fork);
@@ -377,7 +381,20 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     k_m2_streams<<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     const uint32_t gbpt = (max_n + 255) / 256;
     k_m2_gray_syms<<<total * gbpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, gbpt, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
-    k_rans1_encode<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2);
+    if (getenv("XPNG_NARROW_RANS") || ((uint64_t)total * M2_STREAMS <= 2048 && !getenv("XPNG_WIDE_RANS"))) {
+        k_rans1_encode<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2);
+    } else {  // every lane a chain: prep -> chains (small and big alphabets) -> finish
+        if (!c->d_w1prep) {
+            if (hipMalloc((void **)&c->d_w1prep, VN * M2_SLOTS * sizeof(W1Prep)) != hipSuccess ||
+                hipMalloc((void **)&c->d_w1tab, VN * M2_SLOTS * W1_TAB_BYTES) != hipSuccess ||
+                hipMalloc((void **)&c->d_w1F, VN * M2_SLOTS * 512) != hipSuccess)
+                return fail("hipMalloc failed (mode-2 wide encode workspace)");
+        }
+        k_rans1_prep<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2, c->d_w1prep, c->d_w1tab, c->d_w1F);
+        k_rans1_chain<true><<<((total + 15) / 16) * W1_BIG_SLOTS, 64, 0, s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
+        k_rans1_chain<false><<<((total + 31) / 32) * W1_SMALL_SLOTS, 64, 0, s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
+        k_rans1_finish<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2, c->d_w1prep, c->d_w1F);
+    }
     k_m2_select<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, c->d_flags2, c->d_blk2, c->d_mt2, c->d_tile_sz);
     k_m2_bits<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2);
     k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
