@@ -290,19 +290,20 @@ def test_batch_kernels_forced_on_small_inputs(gpu, manifest, po, tmp_path, monke
     monkeypatch.setenv("XPNG_WIDE_RANS", "1")
     checked = 0
     for name, ent in small_entries(manifest):
-        g = ent.get("L1")
-        if g is None:
-            continue
         raster = golden_raster(name, ent)
-        out = tmp_path / "o.xpng"
-        gpu.store(1, raster, str(out))
-        data = out.read_bytes()
-        assert len(data) == g["size"] and md5(data) == g["md5"], name
-        back = gpu.load(str(out))
         want = np.ascontiguousarray(po.normalize_rgba(raster))  # (what the file holds: hidden colours zeroed, opaque alpha dropped)
-        assert back.shape == want.shape and np.array_equal(back, want), name
-        checked += 1
-    assert checked >= 100
+        for level in (1, 2):   # level 2: the wide rANS v1 kernels (rans1_wide.hpp, rans1_wide_dec.hpp)
+            g = ent.get(f"L{level}")
+            if g is None:
+                continue
+            out = tmp_path / "o.xpng"
+            gpu.store(level, raster, str(out))
+            data = out.read_bytes()
+            assert len(data) == g["size"] and md5(data) == g["md5"], (name, level)
+            back = gpu.load(str(out))
+            assert back.shape == want.shape and np.array_equal(back, want), (name, level)
+            checked += 1
+    assert checked >= 200
     from xpng_amd.synth import synth_raster
     rng = np.random.default_rng(11)
     raster = synth_raster("photo", 700, 500, True)
@@ -427,3 +428,32 @@ def test_extreme_aspect_ratios(gpu, po, monkeypatch, force_wide):
         assert ctx.decode_status() == 0
         assert np.array_equal(d_o[: w * h * ch].cpu().numpy().reshape(h, w, ch), r), (w, h, a)
         ctx.close()
+
+
+def test_mode2_large_batch_takes_the_wide_path_and_matches(gpu, po):
+    """Level 2 (RGB) in a batch big enough to select the wide rANS v1 kernels by itself; colour, gray and single-colour tiles."""
+    import torch
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import special_cases, synth_raster
+    mixed = dict(special_cases())["mixed_tiles"]                      # 1000 x 900: colour, gray and single-colour tiles
+    h, w, _ = mixed.shape
+    base = [mixed, synth_raster("photo", w, h, False, seed=3), synth_raster("noise", w, h, False, seed=5)]
+    B = 33
+    ctx = gpu.Context(w, h, 3, batch=B)
+    assert ctx.n_tiles * 17 * B > 2048
+    d_r = [torch.from_numpy(np.ascontiguousarray(base[i % 3])).cuda() for i in range(B)]
+    d_b = [torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    lens = ctx.encode_device_batch(2, [t.data_ptr() for t in d_r], [t.data_ptr() for t in d_b])
+    want = [po.encode_tiles(2, np.ascontiguousarray(r)) for r in base]
+    offs = []
+    for i in range(B):
+        blob = d_b[i][:lens[i]].cpu().numpy().tobytes()
+        assert blob == want[i % 3], i
+        offs.append(walk_tile_offsets(blob, ctx.n_tiles)[0])
+    d_o = [torch.zeros(w * h * 3 + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    ctx.decode_device_batch(2, [t.data_ptr() for t in d_b], lens, offs, [t.data_ptr() for t in d_o])
+    torch.cuda.synchronize()
+    assert ctx.decode_status() == 0
+    for i in range(B):
+        assert np.array_equal(d_o[i][: w * h * 3].cpu().numpy().reshape(h, w, 3), base[i % 3]), i
+    ctx.close()

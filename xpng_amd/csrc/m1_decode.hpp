@@ -36,6 +36,9 @@ struct DecodeWs {
     uint64_t cap_tiles = 0, cap_plane = 0;
     WDec *d_wdec = nullptr;              // wide rANS decode: per (tile, stream) descriptors and decode tables
     uint8_t *d_dtab = nullptr;
+    WDec *d_wdec2 = nullptr;             // the same for mode 2 (21 slots per tile), allocated on first use
+    uint8_t *d_dtab2 = nullptr;
+    uint64_t cap2 = 0;
     std::vector<uint64_t> last_off;      // tile offsets already resident in d_off (skip the upload when unchanged)
     uint32_t last_t0 = 0;
     hipStream_t side = nullptr;          // alpha branch runs beside the nl-context branch
@@ -46,7 +49,7 @@ struct DecodeWs {
     uint32_t *d_resid = nullptr, *d_resid_alloc = nullptr;  // d_resid = d_resid_alloc + 16: k_dec_recon_band reads up to 3 words before a tile's first
 };
 inline void decode_ws_free(DecodeWs &w) {
-    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc, w.d_wdec, w.d_dtab};
+    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc, w.d_wdec, w.d_dtab, w.d_wdec2, w.d_dtab2};
     for (void *q : p) if (q) (void)hipFree(q);
     if (w.side) (void)hipStreamDestroy(w.side);
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);

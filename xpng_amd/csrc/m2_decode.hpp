@@ -378,6 +378,10 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
     }
 }
 
+inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t total, const M2DecTile *d_info2, const TileDesc *d_tiles,
+                          TileSel sel, const M2Blk *d_blk2, const uint16_t *d_tabs2, uint8_t *d_scratch2, const uint64_t *d_sbase2,
+                          hipStream_t s, std::string &err);  // rans1_wide_dec.hpp
+
 // Launch the mode-2 decode of tiles [t0, t1) of every image of the batch (RGB only).
 inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
                             uint32_t max_w, uint32_t max_h,
@@ -391,8 +395,10 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const uint64_t bpr = W * 3;
     if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }
     k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2, d_status);
-    k_rans1_decode<14><<<total * M2_STREAMS, 64, 0, s>>>(d_info2, d_tiles, sel, 0, M2_STREAMS, d_blk2, d_tabs2, d_scratch2, d_sbase2);
-    k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
+    if (getenv("XPNG_NARROW_RANS") || ((uint64_t)total * M2_STREAMS <= 2048 && !getenv("XPNG_WIDE_RANS"))) {
+        k_rans1_decode<14><<<total * M2_STREAMS, 64, 0, s>>>(d_info2, d_tiles, sel, 0, M2_STREAMS, d_blk2, d_tabs2, d_scratch2, d_sbase2);
+        k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
+    } else if (m2_wide_decode(ws, B, n_tiles, total, d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, s, err)) return 1;
     k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);
     k_m2_dec_resid<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
     uint32_t free_ew, rthreads, rlds;

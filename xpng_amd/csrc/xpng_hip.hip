@@ -21,6 +21,7 @@
 #include "rans2.hpp"
 #include "rans2_wide.hpp"
 #include "rans1_wide.hpp"
+#include "rans1_wide_dec.hpp"
 #include "tile_container.hpp"
 
 using namespace xpng;
