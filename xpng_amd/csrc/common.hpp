@@ -94,6 +94,18 @@ __device__ __forceinline__ uint32_t swap_pair(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
 }
 
+// inclusive prefix sum over the 64 lanes with DPP only (row_shr 1/2/4/8 inside each row of 16, then row_bcast15 / row_bcast31
+// carry the row totals): 6 VALU instructions, where six __shfl_up steps are six ds_bpermute round trips through the LDS unit
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2 and 3
+    return v;
+}
+
 // force a wave-uniform value into an SGPR (loop cursors derived from ballots stay scalar: SALU arithmetic and
 // s_cbranch instead of VALU + exec-mask branches)
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }

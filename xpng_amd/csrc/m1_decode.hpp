@@ -228,11 +228,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
         const uint32_t f0 = b + 0 < N ? Fs[b + 0] : 0, f1 = b + 1 < N ? Fs[b + 1] : 0, f2 = b + 2 < N ? Fs[b + 2] : 0, f3 = b + 3 < N ? Fs[b + 3] : 0;
         const uint32_t tot = f0 + f1 + f2 + f3;
         uint32_t incl = tot;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const uint32_t v = __shfl_up(incl, dd);
-            if ((int)lane >= dd) incl += v;
-        }
+        incl = wave_scan_incl(incl);
         const uint32_t c0 = incl - tot, c1 = c0 + f0, c2 = c1 + f1, c3 = c2 + f2;
         if (b + 0 < N) fc[b + 0] = f0 | (c0 << 16);
         if (b + 1 < N) fc[b + 1] = f1 | (c1 << 16);
@@ -372,11 +368,7 @@ __global__ __launch_bounds__(THREADS) void k_dec_alpha(const DecTile *__restrict
         const uint32_t y = y0 + tid;
         const uint32_t dv = y < t.h ? (uint32_t)zz_dec(sy[(uint64_t)y * t.w - 1]) & 255u : 0u;
         uint32_t incl = dv;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const uint32_t v = __shfl_up(incl, dd);
-            if ((int)lane >= dd) incl += v;
-        }
+        incl = wave_scan_incl(incl);
         if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
         uint32_t base = s_carry;
@@ -394,11 +386,7 @@ __global__ __launch_bounds__(THREADS) void k_dec_alpha(const DecTile *__restrict
             const uint32_t x = x0 + lane;
             const uint32_t dv = x < t.w ? (uint32_t)zz_dec(sy[(uint64_t)y * t.w + x - 1]) & 255u : 0u;
             uint32_t incl = dv;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t v = __shfl_up(incl, dd);
-                if ((int)lane >= dd) incl += v;
-            }
+            incl = wave_scan_incl(incl);
             if (x < t.w) al[(uint64_t)y * t.w + x] = (uint8_t)(carry + incl);
             carry = (carry + __shfl(incl, 63)) & 255u;
         }
@@ -638,11 +626,7 @@ __global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict
         const uint32_t nl = coded ? nls[cbase + rank] : 0;
         const uint32_t len = 3 * nl;
         uint32_t incl = len;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const uint32_t v = __shfl_up(incl, dd);
-            if ((int)lane >= dd) incl += v;
-        }
+        incl = wave_scan_incl(incl);
         if (lane == 63) s_wb[wv] = incl;
         __syncthreads();
         uint32_t bbase = run_bits, btot = 0;

@@ -423,11 +423,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
         // (iii) bit lengths: inclusive scan inside the wave
         const uint32_t len = coded ? 3 * nlv : 0;
         uint32_t incl = len;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += v;
-        }
+        incl = wave_scan_incl(incl);
         if (lane == 63) s_wave_bits[wv] = incl;
         __syncthreads();  // (A) wave_last / wave_bits visible
 

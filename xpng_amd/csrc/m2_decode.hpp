@@ -150,11 +150,7 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
         const uint32_t f0 = b + 0 < Nnom ? F16[b + 0] : 0, f1 = b + 1 < Nnom ? F16[b + 1] : 0, f2 = b + 2 < Nnom ? F16[b + 2] : 0, f3 = b + 3 < Nnom ? F16[b + 3] : 0;
         const uint32_t tot = f0 + f1 + f2 + f3;
         uint32_t incl = tot;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const uint32_t v = __shfl_up(incl, dd);
-            if ((int)lane >= dd) incl += v;
-        }
+        incl = wave_scan_incl(incl);
         const uint32_t c0 = incl - tot, c1 = c0 + f0, c2 = c1 + f1, c3 = c2 + f2;
         if (b + 0 < Nnom) fc[b + 0] = f0 | (c0 << 16);
         if (b + 1 < Nnom) fc[b + 1] = f1 | (c1 << 16);

@@ -105,11 +105,7 @@ __device__ inline void rans_tables(uint32_t *hist, uint32_t *cum, EncSym *tab, u
         uint32_t h2 = b + 2 < N ? hist[b + 2] : 0, h3 = b + 3 < N ? hist[b + 3] : 0;
         const uint32_t tot = h0 + h1 + h2 + h3;
         uint32_t incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += v;
-        }
+        incl = wave_scan_incl(incl);
         const uint32_t ex = incl - tot;
         const uint32_t c1 = ex + h0, c2 = c1 + h1, c3 = c2 + h2, c4 = c3 + h3;  // cum[b+1..b+4]
         if (lane == 0) cum[0] = 0;
