@@ -121,7 +121,7 @@ def main():
 
     import xpng_amd
     from xpng_amd.api import walk_tile_offsets
-    from xpng_amd.shard import band_rows, gather_blobs_batch, tile_table, weighted_tile_ranges
+    from xpng_amd.shard import band_rows, gather_blobs_packed, image_from_packs, tile_table, weighted_tile_ranges
     from xpng_amd.synth import seven_header, synth_raster_torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,16 +212,22 @@ def main():
     verified = {"roundtrip": bool(ok), "images_verified": B}
     use_host = world > 1 and args.backend != "nccl"
 
-    def exchange(bufs=None):  # the one exchange of the path: every rank's B blobs -> rank 0 (RCCL send/recv; no collective on the data path)
+    len_table = [None]
+
+    def exchange(bufs=None, scratch=None):
+        # the one exchange of the path: every rank packs its B blobs and sends ONE message to rank 0 (RCCL send/recv, 7 links
+        # into rank 0 on a node; no collective on the data path).  The first call learns the (world x B) length table; later
+        # calls pass it in, so nothing here synchronises with the host and the exchange queues behind the encode on its stream
         bufs = d_blobs_all if bufs is None else bufs
-        if not use_host:
-            return gather_blobs_batch(bufs, lens_b)
-        outs, table = gather_blobs_batch([t[:lens_b[i]].cpu() for i, t in enumerate(bufs)], lens_b)
-        return outs, table
+        if use_host:
+            bufs = [t[:lens_b[i]].cpu() for i, t in enumerate(bufs)]
+        packs, table = gather_blobs_packed(bufs, lens_b, table=len_table[0], scratch=scratch)
+        len_table[0] = table
+        return packs, table
 
     if world > 1:
-        outs, table = exchange()
-        gathered, lens = (outs[0] if rank == 0 else None), [row[0] for row in table]
+        packs, table = exchange()
+        gathered, lens = (image_from_packs(packs, table, 0) if rank == 0 else None), [row[0] for row in table]
     else:
         gathered, lens = d_blobs_all[0][:n], [n]
     if rank == 0:
@@ -246,7 +252,7 @@ def main():
         sl["ctx"].encode_device_batch(1, rast_ptrs, sl["blob_ptrs"], t0, t1, stream=sh, sync=False)
         if world > 1:
             with torch.cuda.stream(sl["stream"]):
-                exchange(sl["blobs"])  # tile bytes are deterministic: the lengths are the ones verified above
+                exchange(sl["blobs"], sl.setdefault("xchg", {}))  # tile bytes are deterministic: the lengths are the ones verified above
         sl["ctx"].decode_device_batch(1, sl["blob_ptrs"], lens_b, offs_b, sl["back_ptrs"], t0, t1, stream=sh)
 
     # ---- per-stage rates on this rank (HIP events on the stream the kernels run on)
@@ -321,8 +327,9 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' {'RGBA8' if alpha else 'RGB8'}, level -1 (FAST), tile encode + decode, rasters and blobs resident in HBM",
                        "batch": B, "pipeline_slots": P, "tiles": len(tiles), "tiles_per_rank": t1 - t0, "share_px": my_px,
-                       "parallelism": f"tile-range x{world}" + (f" + gatherv of blobs to rank 0 ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
-                       "compressed_bytes": int(sum(lens)), "distinct_rasters_per_launch": B},
+                       "parallelism": f"tile-range x{world}" + (f" + one packed send of the step's blobs per rank to rank 0 ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
+                       "compressed_bytes": int(sum(lens)), "distinct_rasters_per_launch": B,
+                       "hbm_in_use_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30, 1)},
             "verified": verified,
             "single_image_encode_mpx_s": round(my_px / enc_ms / 1e3, 1), "single_image_decode_mpx_s": round(my_px / dec_ms / 1e3, 1),
             "single_image_encode_ms": round(enc_ms, 3), "single_image_decode_ms": round(dec_ms, 3),

@@ -82,7 +82,14 @@ def _worker_batch(rank, world, port, q):
         bufs.append(torch.from_numpy(np.frombuffer(blob + b"\0" * 32, np.uint8).copy()))
         lens.append(len(blob))
     outs, table = gather_blobs_batch(bufs, lens)
+    # the one-message-per-rank form, first discovering the lengths, then with the table known (no length exchange)
+    from xpng_amd.shard import gather_blobs_packed, image_from_packs
+    packs, table2 = gather_blobs_packed(bufs, lens)
+    packs3, table3 = gather_blobs_packed(bufs, lens, table=table2)
     if rank == 0:
+        assert table2 == table and table3 == table
+        for pk in (packs, packs3):
+            assert [image_from_packs(pk, table, b).numpy().tobytes() for b in range(B)] == [o.numpy().tobytes() for o in outs]
         q.put(([o.numpy().tobytes() for o in outs], table))
     dist.barrier()
     dist.destroy_process_group()

@@ -47,14 +47,25 @@ struct DecodeWs {
     uint64_t *d_off = nullptr;
     uint8_t *d_ctxsym = nullptr, *d_asym = nullptr, *d_alpha = nullptr, *d_nlseq = nullptr;
     uint32_t *d_resid = nullptr, *d_resid_alloc = nullptr;  // d_resid = d_resid_alloc + 16: k_dec_recon_band reads up to 3 words before a tile's first
+    // The five symbol / residual planes (8 B per pixel) are carved out of `arena` when it is big enough: the context hands
+    // in its encode stream scratch, which no decode kernel reads and no encode kernel touches while a decode of the same
+    // context runs (calls on one context are ordered on one stream).  planes_in_arena: those pointers are not ours to free.
+    uint8_t *arena = nullptr;
+    uint64_t arena_bytes = 0;
+    bool planes_in_arena = false;
 };
 inline void decode_ws_free(DecodeWs &w) {
-    void *p[] = {w.d_info, w.d_off, w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc, w.d_wdec, w.d_dtab, w.d_wdec2, w.d_dtab2};
+    void *p[] = {w.d_info, w.d_off, w.d_wdec, w.d_dtab, w.d_wdec2, w.d_dtab2};
     for (void *q : p) if (q) (void)hipFree(q);
+    void *planes[] = {w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc};
+    for (void *q : planes) if (q && !w.planes_in_arena) (void)hipFree(q);
     if (w.side) (void)hipStreamDestroy(w.side);
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
+    uint8_t *arena = w.arena;
+    const uint64_t arena_bytes = w.arena_bytes;
     w = DecodeWs();  // (also clears last_off)
+    w.arena = arena; w.arena_bytes = arena_bytes;
 }
 
 // unaligned-safe little-endian u32 load from global memory (tile blobs are only byte-aligned after a raw RGB tile)
@@ -931,10 +942,22 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
     auto bad = [&](const char *m) { err = m; return 1; };
     if (ws.cap_tiles < (uint64_t)B * n_tiles || ws.cap_plane < plane) {
         decode_ws_free(ws);
+        const uint64_t sz[5] = {rup(plane + 8192, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(4 * plane + 1024, 256)};
+        void *pl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (ws.arena && ws.arena_bytes >= sz[0] + sz[1] + sz[2] + sz[3] + sz[4] + 256 && !getenv("XPNG_NO_ARENA")) {
+            uint8_t *q = reinterpret_cast<uint8_t *>(rup(reinterpret_cast<uintptr_t>(ws.arena), 256));
+            for (int i = 0; i < 5; i++) { pl[i] = q; q += sz[i]; }
+            ws.planes_in_arena = true;
+        } else {
+            for (int i = 0; i < 5; i++)
+                if (hipMalloc(&pl[i], sz[i]) != hipSuccess) {
+                    for (int j = 0; j < i; j++) (void)hipFree(pl[j]);
+                    return bad("hipMalloc failed (decode workspace)");
+                }
+        }
+        ws.d_ctxsym = (uint8_t *)pl[0]; ws.d_asym = (uint8_t *)pl[1]; ws.d_alpha = (uint8_t *)pl[2]; ws.d_nlseq = (uint8_t *)pl[3];
+        ws.d_resid_alloc = (uint32_t *)pl[4];
         if (hipMalloc((void **)&ws.d_info, (uint64_t)B * n_tiles * sizeof(DecTile)) != hipSuccess || hipMalloc((void **)&ws.d_off, (uint64_t)B * n_tiles * 8) != hipSuccess ||
-            hipMalloc((void **)&ws.d_ctxsym, plane + 8192) != hipSuccess || hipMalloc((void **)&ws.d_asym, plane + 64) != hipSuccess ||
-            hipMalloc((void **)&ws.d_alpha, plane + 64) != hipSuccess || hipMalloc((void **)&ws.d_nlseq, plane + 64) != hipSuccess ||
-            hipMalloc((void **)&ws.d_resid_alloc, 4 * plane + 1024) != hipSuccess ||
             hipMalloc((void **)&ws.d_wdec, (uint64_t)B * n_tiles * 10 * sizeof(WDec)) != hipSuccess ||
             hipMalloc((void **)&ws.d_dtab, (uint64_t)B * n_tiles * 10 * WD_TAB_MAX) != hipSuccess)
             return bad("hipMalloc failed (decode workspace)");

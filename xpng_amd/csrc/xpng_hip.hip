@@ -178,6 +178,8 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
     ALLOC(c->d_tiles, VN * sizeof(TileDesc));
     ALLOC(c->d_planes, 5 * c->plane_stride + 8192);   // + slack: LDS-ring staging reads whole 1 KB units
     ALLOC(c->d_scratch, c->scratch_img * batch + 8192);
+    c->dec.arena = c->d_scratch;   // decode keeps its symbol / residual planes in the encode stream scratch (DecodeWs::arena)
+    c->dec.arena_bytes = c->scratch_img * batch + 8192;
     ALLOC(c->d_sums, VN * 16);
     ALLOC(c->d_ctx_n, VN * 9 * 4);
     ALLOC(c->d_k_n, VN * 4);

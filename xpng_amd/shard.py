@@ -153,3 +153,71 @@ def gather_blobs_batch(locals_, lens_local, group=None, dst: int = 0):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return None, lens
+
+
+def gather_blobs_packed(locals_, lens_local, table=None, group=None, dst: int = 0, scratch=None):
+    """gatherv for a batch with ONE message per rank: a rank packs its B blobs back to back (one device copy kernel) and sends
+    the pack to rank `dst`; rank `dst` receives world-1 packs (7 concurrent xGMI links on an 8-GPU node) and returns
+    (packs in rank order, table).  `table` is the (world x B) byte-length table; when the caller already knows it (lengths
+    are deterministic for a given raster, and an encode that returns lengths has them on the host anyway) no length
+    all-gather and no host synchronisation happens here, so the exchange queues behind the encode on the current stream.
+    Image b of the file is the concatenation over ranks r of packs[r][off(r,b) : off(r,b) + table[r][b]] with
+    off(r,b) = sum(table[r][:b]) - see `image_from_packs`.  `scratch` (a dict the caller keeps, one per pipeline slot) makes
+    the pack and receive buffers persistent, so a steady-state step allocates nothing."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = len(locals_)
+    dev = locals_[0].device
+    if table is None:
+        mine = torch.tensor(list(lens_local), dtype=torch.int64, device=dev)
+        flat = torch.zeros(world * B, dtype=torch.int64, device=dev)
+        if dev.type == "cuda":
+            dist.all_gather_into_tensor(flat, mine, group=group)
+        else:
+            dist.all_gather(list(flat.split(B)), mine, group=group)
+        table = [[int(v) for v in row] for row in flat.view(world, B).tolist()]
+    if [int(v) for v in table[rank]] != [int(v) for v in lens_local]:
+        raise ValueError("length table row of this rank does not match its blob lengths")
+    def buffer(key, nbytes):
+        if scratch is None:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        t = scratch.get(key)
+        if t is None or t.numel() != nbytes or t.device != dev:
+            t = scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return t
+
+    pack = buffer("pack", sum(lens_local))
+    if pack.numel():
+        torch.cat([locals_[b][:lens_local[b]] for b in range(B)], out=pack)
+    if world == 1:
+        return [pack], table
+    if rank == dst:
+        packs, ops = [], []
+        for r in range(world):
+            if r == dst:
+                packs.append(pack)
+                continue
+            buf = buffer(("recv", r), sum(table[r]))
+            packs.append(buf)
+            if buf.numel():
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return packs, table
+    if pack.numel():
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, pack, dst, group)]):
+            req.wait()
+    return None, table
+
+
+def image_from_packs(packs, table, b: int):
+    """Tile blobs of image b in file order (rank-ordered tile ranges) out of the per-rank packs `gather_blobs_packed` returns."""
+    import torch
+    segs = []
+    for r, pk in enumerate(packs):
+        o = sum(table[r][:b])
+        segs.append(pk[o:o + table[r][b]])
+    return torch.cat(segs)
