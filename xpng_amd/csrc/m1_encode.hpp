@@ -377,19 +377,25 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
                                                            const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                            uint8_t *__restrict__ scratch, uint32_t *__restrict__ ctx_n,
                                                            uint32_t *__restrict__ k_n) {
+    // One workgroup walks a tile in raster order, ST_THREADS * 4 pixels per iteration: a lane owns 4 consecutive pixels
+    // (one dword of each plane).  Per iteration: the previous-coded-nl chain (pl), a packed prefix sum of the nine
+    // per-context counts (three 10-bit fields per word, three DPP scans), one scan of the bit lengths, byte stores into the
+    // context streams and up to 96 bits per lane OR-ed into an LDS bit window that is flushed to k as whole words.
     const uint32_t tile = vtile(sel, blockIdx.x);
     const TileDesc t = tiles[tile];
     const uint8_t *__restrict__ raster = rasters[t.img];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint8_t *pnl = planes + t.pbase, *pr_ = planes + plane_stride + t.pbase;
-    const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;
+    const uint32_t *pnl = reinterpret_cast<const uint32_t *>(planes + t.pbase), *pr_ = reinterpret_cast<const uint32_t *>(planes + plane_stride + t.pbase);
+    const uint32_t *pg = reinterpret_cast<const uint32_t *>(planes + 2 * plane_stride + t.pbase), *pb = reinterpret_cast<const uint32_t *>(planes + 3 * plane_stride + t.pbase);
     uint8_t *sc = scratch + t.sbase;
     uint32_t *kw = reinterpret_cast<uint32_t *>(sc + off_kw(t.n));
+    const uint32_t cap = (uint32_t)ctx_cap(t.n);
 
-    constexpr int ST_WAVES = ST_THREADS / 64, ST_WORDS = ST_THREADS * 24 / 32 + 4;
+    constexpr int ST_WAVES = ST_THREADS / 64, ST_PX = ST_THREADS * 4, ST_WORDS = ST_PX * 24 / 32 + 4, ST_ROUNDS = (ST_WORDS + ST_THREADS - 1) / ST_THREADS;
     __shared__ uint32_t s_bits[ST_WORDS];
     __shared__ uint32_t s_run_cnt[9];
     __shared__ uint32_t s_wave_cnt[ST_WAVES][9];
+    __shared__ volatile uint32_t s_base[ST_WAVES][16];
     __shared__ uint32_t s_wave_bits[ST_WAVES];
     __shared__ uint32_t s_wave_last[ST_WAVES];
 
@@ -407,23 +413,44 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
         run_bits = 24; wbase = 0;
     }
     const uint64_t lt = lanemask_lt();
+    // field of context c in the packed counters: word c / 3, bits [10 * (c % 3), +10)
+    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);
 
-    for (uint32_t i0 = 0; i0 < t.n; i0 += ST_THREADS) {
-        const uint32_t i = i0 + tid;
-        const uint32_t nlv = i < t.n ? pnl[i] : NL_NONE;
-        const bool coded = nlv != NL_NONE;
-        const uint64_t mask = __ballot(coded);
+    // planes are read one iteration ahead (dwords; the planes carry >= 192 bytes of slack behind a tile)
+    uint32_t nx_nl = 0xFFFFFFFFu, nx_r = 0, nx_g = 0, nx_b = 0;
+    if (4 * tid < t.n) { nx_nl = pnl[tid]; nx_r = pr_[tid]; nx_g = pg[tid]; nx_b = pb[tid]; }
+
+    for (uint32_t i0 = 0; i0 < t.n; i0 += ST_PX) {
+        const uint32_t i = i0 + 4 * tid;
+        uint32_t nl4 = nx_nl;
+        const uint32_t r4 = nx_r, g4 = nx_g, b4 = nx_b;
+        {
+            const uint32_t in = i + ST_PX;
+            nx_nl = 0xFFFFFFFFu;
+            if (in < t.n) { nx_nl = pnl[in >> 2]; nx_r = pr_[in >> 2]; nx_g = pg[in >> 2]; nx_b = pb[in >> 2]; }
+        }
+        if (i < t.n && t.n - i < 4) nl4 |= 0xFFFFFFFFu << (8 * (t.n - i));  // pixels past the tile: not coded
+        uint32_t nl[4], len[4];
+        bool coded[4];
+        uint32_t lastnl = NL_NONE, lane_len = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            nl[j] = (nl4 >> (8 * j)) & 255u;
+            coded[j] = nl[j] != NL_NONE;
+            lastnl = coded[j] ? nl[j] : lastnl;
+            len[j] = coded[j] ? 3 * nl[j] : 0;
+            lane_len += len[j];
+        }
+        const uint64_t mask = __ballot(nl4 != 0xFFFFFFFFu);
         const uint64_t lower = mask & lt;
-        // (i) previous coded nl inside the wave
+        // (i) previous coded nl: inside the wave by a lane fetch, across waves through LDS
         const int src_last = mask ? 63 - __clzll((long long)mask) : 0;
-        const uint32_t wave_last = __shfl(nlv, src_last);
+        const uint32_t wave_last = __shfl(lastnl, src_last);
         if (lane == 0) s_wave_last[wv] = mask ? wave_last : NL_NONE;
         const int src_prev = lower ? 63 - __clzll((long long)lower) : 0;
-        const uint32_t prev_in_wave = __shfl(nlv, src_prev);
+        const uint32_t prev_in_wave = __shfl(lastnl, src_prev);
         // (iii) bit lengths: inclusive scan inside the wave
-        const uint32_t len = coded ? 3 * nlv : 0;
-        uint32_t incl = len;
-        incl = wave_scan_incl(incl);
+        const uint32_t incl = wave_scan_incl(lane_len);
         if (lane == 63) s_wave_bits[wv] = incl;
         __syncthreads();  // (A) wave_last / wave_bits visible
 
@@ -434,42 +461,76 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
             if (wl != NL_NONE) new_run_pl = wl;
             bits_total += wb;
         }
-        const uint32_t pl = lower ? prev_in_wave : carry;
-        // (ii) rank inside the context stream
-        uint32_t my_rank = 0, my_cnt = 0;
+        // (ii) pl of each pixel and the lane's packed per-context counts
+        uint32_t pl[4], sh[4], inc[4][3], w0 = 0, w1 = 0, w2s = 0;
+        {
+            uint32_t p = lower ? prev_in_wave : carry;
 #pragma unroll
-        for (uint32_t c = 0; c < 9; c++) {
-            const uint64_t m = __ballot(coded && pl == c);
-            if (pl == c) my_rank = (uint32_t)__popcll(m & lt);
-            if (lane == c) my_cnt = (uint32_t)__popcll(m);
-        }
-        if (lane < 9) s_wave_cnt[wv][lane] = my_cnt;
-        __syncthreads();  // (B) per-wave context counts visible
-
-        if (coded) {
-            uint32_t base = s_run_cnt[pl];
-            for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave_cnt[w2][pl];
-            sc[off_ctx(t.n, (int)pl) + base + my_rank] = (uint8_t)nlv;
-            if (nlv) {
-                const uint32_t v = ((uint32_t)pr_[i] << (2 * nlv)) | ((uint32_t)pg[i] << nlv) | (uint32_t)pb[i];
-                const uint32_t ob = (run_bits & 31) + bit_base + (incl - len);
-                const uint32_t wi = ob >> 5;
-                const int sh = 32 - (int)(ob & 31) - (int)len;
-                if (sh >= 0) atomicOr(&s_bits[wi], v << sh);
-                else { atomicOr(&s_bits[wi], v >> (-sh)); atomicOr(&s_bits[wi + 1], v << (32 + sh)); }
+            for (int j = 0; j < 4; j++) {
+                pl[j] = p;
+                const uint32_t q = (p * 11u) >> 5;
+                sh[j] = 10u * (p - 3u * q);
+                const uint32_t one = coded[j] ? 1u << sh[j] : 0u;
+                inc[j][0] = q == 0 ? one : 0u; inc[j][1] = q == 1 ? one : 0u; inc[j][2] = q == 2 ? one : 0u;
+                w0 += inc[j][0]; w1 += inc[j][1]; w2s += inc[j][2];
+                p = coded[j] ? nl[j] : p;
             }
+        }
+        const uint32_t x0 = wave_scan_incl(w0), x1 = wave_scan_incl(w1), x2 = wave_scan_incl(w2s);
+        {
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, 63),
+                           t2 = (uint32_t)__builtin_amdgcn_readlane((int)x2, 63);
+            const uint32_t word = myq == 0 ? t0 : (myq == 1 ? t1 : t2);
+            if (lane < 9) s_wave_cnt[wv][lane] = (word >> mysh) & 1023u;
+        }
+        __syncthreads();  // (B) per-wave context counts visible
+        if (lane < 9) {   // this wave's base position in each context stream (wave-private LDS row: DS ops of a wave stay in order)
+            uint32_t base = s_run_cnt[lane];
+            for (uint32_t w = 0; w < wv; w++) base += s_wave_cnt[w][lane];
+            s_base[wv][lane] = base;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t e0 = x0 - w0, e1 = x1 - w1, e2 = x2 - w2s;  // exclusive lane prefixes, advanced pixel by pixel below
+        unsigned __int128 frame = 0;
+        uint32_t pos = (run_bits & 31) + bit_base + (incl - lane_len);
+        const uint32_t wi = pos >> 5;
+        pos &= 31;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (coded[j]) {
+                const uint32_t e = inc[j][0] ? e0 : (inc[j][1] ? e1 : e2);
+                const uint32_t rank = (e >> sh[j]) & 1023u;
+                sc[pl[j] * cap + s_base[wv][pl[j]] + rank] = (uint8_t)nl[j];
+            }
+            e0 += inc[j][0]; e1 += inc[j][1]; e2 += inc[j][2];
+            const uint32_t n1 = nl[j] & 15u;  // (NL_NONE has len 0: v is masked out below)
+            const uint32_t v = len[j] ? ((((r4 >> (8 * j)) & 255u) << (2 * n1)) | (((g4 >> (8 * j)) & 255u) << n1) | ((b4 >> (8 * j)) & 255u)) : 0u;
+            frame |= (unsigned __int128)v << ((128u - pos - len[j]) & 127u);
+            pos += len[j];
+        }
+        {
+            const uint32_t f0 = (uint32_t)(frame >> 96), f1 = (uint32_t)(frame >> 64), f2 = (uint32_t)(frame >> 32), f3 = (uint32_t)frame;
+            if (f0) atomicOr(&s_bits[wi], f0);
+            if (f1) atomicOr(&s_bits[wi + 1], f1);
+            if (f2) atomicOr(&s_bits[wi + 2], f2);
+            if (f3) atomicOr(&s_bits[wi + 3], f3);
         }
         __syncthreads();  // (C) bit window complete
 
         const uint32_t nfull = ((run_bits & 31) + bits_total) >> 5;
-        uint32_t keep = 0, carry_word = 0;
-        if (tid < ST_WORDS) keep = s_bits[tid];
+        uint32_t keep[ST_ROUNDS], carry_word = 0;
+#pragma unroll
+        for (int k = 0; k < ST_ROUNDS; k++) { const uint32_t j = tid + k * ST_THREADS; keep[k] = j < (uint32_t)ST_WORDS ? s_bits[j] : 0u; }
         if (tid == 0) carry_word = s_bits[nfull];
         uint32_t tot_c = 0;
-        if (tid < 9) { for (int w2 = 0; w2 < ST_WAVES; w2++) tot_c += s_wave_cnt[w2][tid]; }
+        if (tid < 9) { for (int w = 0; w < ST_WAVES; w++) tot_c += s_wave_cnt[w][tid]; }
         __syncthreads();  // (D) everyone has read the window / counts
-        if (tid < nfull) kw[wbase + tid] = keep;
-        if (tid < ST_WORDS) s_bits[tid] = tid == 0 ? carry_word : 0;
+#pragma unroll
+        for (int k = 0; k < ST_ROUNDS; k++) {
+            const uint32_t j = tid + k * ST_THREADS;
+            if (j < nfull) kw[wbase + j] = keep[k];
+            if (j < (uint32_t)ST_WORDS) s_bits[j] = j == 0 ? carry_word : 0u;
+        }
         if (tid < 9) s_run_cnt[tid] += tot_c;
         run_bits += bits_total; wbase += nfull; run_pl = new_run_pl;
         // the next iteration's barrier (A) orders these LDS writes before their next use
