@@ -612,58 +612,109 @@ __global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint8_t *__restrict__ nlseq,
                                                     uint32_t *__restrict__ resid) {
+    // One workgroup walks a tile in raster order, THREADS * 4 pixels per iteration; a lane owns 4 consecutive pixels: one
+    // dword of the alpha plane (read one iteration ahead), up to 4 consecutive nl symbols, up to 96 bits of k, one 16-byte
+    // store of residual words.  Two wave scans (coded pixels, bit lengths) and two barriers per iteration.
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DecTile d = info[j];
     if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
-    const uint8_t *kbase = d.blob + 8, *kend = kbase + d.kbytes;
-    const uint8_t *al = alpha + t.pbase, *nls = nlseq + t.pbase;
+    const uint8_t *kbase = d.blob + 8;
+    const uint32_t kmis = (uint32_t)(reinterpret_cast<uintptr_t>(kbase) & 3);  // tile blobs are only byte-aligned after a raw RGB tile
+    const uint32_t *kal = reinterpret_cast<const uint32_t *>(kbase - kmis);
+    const uint32_t kwords = (d.kbytes + kmis + 3) >> 2;  // aligned dwords that hold k bytes
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(alpha + t.pbase);
+    const uint32_t *nls = reinterpret_cast<const uint32_t *>(nlseq + t.pbase);
     uint32_t *rs = resid + t.pbase;
-    const int useG = d.type & 1;
-    constexpr uint32_t NW = THREADS / 64;
-    __shared__ uint32_t s_wc[NW], s_wb[NW];
-    uint32_t run_cnt = 0, run_bits = 8 * PXSZ;
-    const uint64_t lt = lanemask_lt();
-    for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
-        const uint32_t i = i0 + tid;
-        bool coded = i < t.n && i > 0;
-        if (PXSZ == 4 && coded) coded = al[i] != 0;
-        const uint64_t m = __ballot(coded);
-        const uint32_t rank = (uint32_t)__popcll(m & lt), wcnt = (uint32_t)__popcll(m);
-        if (lane == 0) s_wc[wv] = wcnt;
+    const bool useG = d.type & 1;
+    constexpr uint32_t NW = THREADS / 64, PX = THREADS * 4;
+    __shared__ uint32_t s_wc[2][NW], s_wb[2][NW];
+    uint32_t run_cnt = 0, run_bits = 8 * PXSZ, par = 0;
+    // (x, y) of the lane's first pixel, advanced by PX pixels per iteration (only the green add-back needs it: tiles >= 4 wide)
+    uint32_t py = (4 * tid) / t.w, px = 4 * tid - py * t.w;
+    const uint32_t dy = PX / t.w, dx = PX - dy * t.w;
+
+    uint32_t nx_a = 0;
+    if (PXSZ == 4 && 4 * tid < t.n) nx_a = al[tid];
+    for (uint32_t i0 = 0; i0 < t.n; i0 += PX, par ^= 1) {
+        const uint32_t i = i0 + 4 * tid;
+        uint32_t a4 = PXSZ == 4 ? nx_a : 0x01010101u;
+        if (PXSZ == 4) { const uint32_t in = i + PX; nx_a = 0; if (in < t.n) nx_a = al[in >> 2]; }
+        if (i >= t.n) a4 = 0;
+        else if (t.n - i < 4) a4 &= 0xFFFFFFFFu >> (8 * (4 - (t.n - i)));  // pixels past the tile
+        if (i == 0) a4 &= 0xFFFFFF00u;                                      // the first pixel is not coded
+        bool coded[4];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { coded[k] = ((a4 >> (8 * k)) & 255u) != 0; cnt += coded[k]; }
+        const uint32_t cincl = wave_scan_incl(cnt);
+        if (lane == 63) s_wc[par][wv] = cincl;
         __syncthreads();
         uint32_t cbase = run_cnt, ctot = 0;
-        for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t v = s_wc[w2]; if (w2 < wv) cbase += v; ctot += v; }
-        const uint32_t nl = coded ? nls[cbase + rank] : 0;
-        const uint32_t len = 3 * nl;
-        uint32_t incl = len;
-        incl = wave_scan_incl(incl);
-        if (lane == 63) s_wb[wv] = incl;
+        for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t v = s_wc[par][w2]; if (w2 < wv) cbase += v; ctot += v; }
+        // the lane's nl symbols: cnt consecutive bytes of the nl sequence
+        uint32_t u = 0;
+        if (cnt) {
+            const uint32_t s0 = cbase + cincl - cnt;
+            const uint32_t lo = nls[s0 >> 2], hi = nls[(s0 >> 2) + 1];
+            u = __builtin_amdgcn_alignbyte(hi, lo, s0 & 3);
+        }
+        uint32_t nl[4], len[4], lane_len = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            nl[k] = coded[k] ? min(u & 255u, 8u) : 0u;
+            u = coded[k] ? u >> 8 : u;
+            len[k] = 3 * nl[k];
+            lane_len += len[k];
+        }
+        const uint32_t bincl = wave_scan_incl(lane_len);
+        if (lane == 63) s_wb[par][wv] = bincl;
         __syncthreads();
         uint32_t bbase = run_bits, btot = 0;
-        for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t v = s_wb[w2]; if (w2 < wv) bbase += v; btot += v; }
+        for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t v = s_wb[par][w2]; if (w2 < wv) bbase += v; btot += v; }
         if (i < t.n) {
-            uint32_t word = 0;
-            if (coded) {
-                int dr = 0, dg = 0, db = 0;
-                if (nl) {
-                    const uint32_t ob = bbase + incl - len;
-                    const uint8_t *wp = kbase + (uint64_t)(ob >> 5) * 4;
-                    const uint64_t two = ((uint64_t)(wp < kend ? ld32u(wp) : 0u) << 32) | (wp + 4 < kend ? ld32u(wp + 4) : 0u);
-                    const uint32_t v = (uint32_t)((two >> (64 - (ob & 31) - len)) & ((1u << len) - 1));
-                    const uint32_t mk = (1u << nl) - 1;
-                    dr = zz_dec((int)(v >> (2 * nl))); dg = zz_dec((int)((v >> nl) & mk)); db = zz_dec((int)(v & mk));
+            // bits [eb - lane_len, eb) of k, right-aligned in s2:s1:s0 (<= 96 bits): the four k words that end at bit eb
+            uint32_t s0 = 0, s1 = 0, s2 = 0;
+            if (lane_len) {
+                const uint32_t eb = bbase + bincl;
+                const int32_t we = (int32_t)((eb - 1) >> 5);
+                uint32_t A[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {  // aligned dwords we-3 .. we+1 of the (possibly misaligned) word array
+                    const int32_t q = we - 3 + k;
+                    A[k] = (q >= 0 && (uint32_t)q < kwords) ? kal[q] : 0u;
                 }
-                const uint32_t y = i / t.w, x = i - y * t.w;
-                if (useG && x > 0 && y > 0) { dr += dg; db += dg; }  // libxpng.c:813
-                // top byte: "coded" marker = the pixel's alpha for RGBA (non-zero exactly when coded), 1 for RGB
-                word = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) |
-                       ((PXSZ == 4 ? (uint32_t)al[i] : 1u) << 24);
+                uint32_t Bw[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) Bw[k] = __builtin_amdgcn_alignbyte(A[k + 1], A[k], kmis);
+                const uint32_t r = (0u - eb) & 31u;  // bits of the last word behind the lane's string
+                s0 = __builtin_amdgcn_alignbit(Bw[2], Bw[3], r);
+                s1 = __builtin_amdgcn_alignbit(Bw[1], Bw[2], r);
+                s2 = __builtin_amdgcn_alignbit(Bw[0], Bw[1], r);
             }
-            rs[i] = word;
+            uint32_t word[4];
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {  // last pixel first: its bits are the lowest
+                const uint32_t v = __builtin_amdgcn_ubfe(s0, 0, len[k]);
+                s0 = __builtin_amdgcn_alignbit(s1, s0, len[k]);
+                s1 = __builtin_amdgcn_alignbit(s2, s1, len[k]);
+                s2 >>= len[k];
+                const uint32_t mk = (1u << nl[k]) - 1;
+                int dr = zz_dec((int)(v >> (2 * nl[k]))), dg = zz_dec((int)((v >> nl[k]) & mk)), db = zz_dec((int)(v & mk));
+                if (useG) {  // green add-back everywhere but row 0 / column 0 (libxpng.c:813)
+                    uint32_t x = px + k, y = py;
+                    if (x >= t.w) { x -= t.w; y++; }
+                    if (x > 0 && y > 0) { dr += dg; db += dg; }
+                }
+                // top byte: "coded" marker = the pixel's alpha for RGBA (non-zero exactly when coded), 1 for RGB
+                const uint32_t w = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) | (((a4 >> (8 * k)) & 255u) << 24);
+                word[k] = coded[k] ? w : 0u;
+            }
+            *reinterpret_cast<u32x4_t *>(rs + i) = u32x4_t{word[0], word[1], word[2], word[3]};
         }
         run_cnt += ctot; run_bits += btot;
-        __syncthreads();
+        px += dx; py += dy;
+        if (px >= t.w) { px -= t.w; py++; }
     }
 }
 
