@@ -390,17 +390,51 @@ __global__ __launch_bounds__(THREADS) void k_dec_alpha(const DecTile *__restrict
         __syncthreads();
     }
     __syncthreads();
-    // ---- rows: each wave scans whole rows left to right, 64 pixels per step
-    for (uint32_t y = wv; y < t.h; y += THREADS / 64) {
-        uint32_t carry = al[(uint64_t)y * t.w];
-        for (uint32_t x0 = 1; x0 < t.w; x0 += 64) {
-            const uint32_t x = x0 + lane;
-            const uint32_t dv = x < t.w ? (uint32_t)zz_dec(sy[(uint64_t)y * t.w + x - 1]) & 255u : 0u;
-            uint32_t incl = dv;
-            incl = wave_scan_incl(incl);
-            if (x < t.w) al[(uint64_t)y * t.w + x] = (uint8_t)(carry + incl);
-            carry = (carry + __shfl(incl, 63)) & 255u;
+    // ---- rows: each wave scans whole rows left to right, 256 pixels per step (a lane owns one aligned dword of the plane);
+    // the symbol dwords and the row's column-0 value are read one step ahead, interior dwords are stored whole
+    if (t.w == 1) return;
+    constexpr uint32_t NWV = THREADS / 64;
+    const uint32_t *sy4 = reinterpret_cast<const uint32_t *>(sy);
+    uint32_t *al4 = reinterpret_cast<uint32_t *>(al);
+    const uint32_t spr = ((t.w + 6) / 4 + 63) / 64;  // steps per row (rows start at any byte alignment)
+    uint32_t y = wv, st = 0, carry = 0;
+    uint32_t n_cur = 0, n_prev = 0, n_c0 = 0;
+    if (y < t.h) {
+        const uint32_t rs = y * t.w, g = (rs >> 2) + lane;
+        if (4 * g < rs + t.w) { n_cur = sy4[g]; n_prev = g ? sy4[g - 1] : 0u; }
+        n_c0 = al[rs];
+    }
+    while (y < t.h) {
+        const uint32_t cur = n_cur, prev = n_prev, c0 = n_c0;
+        const uint32_t rs = y * t.w, re = rs + t.w, g = (rs >> 2) + lane + 64 * st, idx0 = 4 * g;
+        uint32_t ny = y, nst = st + 1;
+        if (nst == spr) { nst = 0; ny = y + NWV; }
+        if (ny < t.h) {
+            const uint32_t nrs = ny * t.w, ng = (nrs >> 2) + lane + 64 * nst;
+            if (4 * ng < nrs + t.w) { n_cur = sy4[ng]; n_prev = ng ? sy4[ng - 1] : 0u; }
+            if (nst == 0) n_c0 = al[nrs];
         }
+        if (st == 0) carry = c0;
+        // deltas of pixels idx0 .. idx0+3 (symbol of pixel i sits at sy[i-1]); pixels outside (rs, re) contribute nothing
+        const uint32_t u = __builtin_amdgcn_alignbyte(cur, prev, 3);
+        uint32_t d4 = ((u >> 1) & 0x7F7F7F7Fu) ^ ((u & 0x01010101u) * 255u);
+        const int32_t lo = (int32_t)rs - (int32_t)idx0 + 1, hi = (int32_t)re - (int32_t)idx0;  // bytes [lo, hi) of the dword are in the row
+        uint32_t mask = lo <= 0 ? 0xFFFFFFFFu : (lo >= 4 ? 0u : 0xFFFFFFFFu << (8 * lo));
+        mask &= hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ~(0xFFFFFFFFu << (8 * hi)));
+        d4 &= mask;
+        const uint32_t p0 = d4 & 255u, p1 = p0 + ((d4 >> 8) & 255u), p2 = p1 + ((d4 >> 16) & 255u), p3 = p2 + (d4 >> 24);
+        const uint32_t incl = wave_scan_incl(p3);
+        const uint32_t base = carry + incl - p3;
+        const uint32_t b0 = (base + p0) & 255u, b1 = (base + p1) & 255u, b2 = (base + p2) & 255u, b3 = (base + p3) & 255u;
+        if (mask == 0xFFFFFFFFu) al4[g] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        else if (mask) {
+            if (mask & 0x000000FFu) al[idx0] = (uint8_t)b0;
+            if (mask & 0x0000FF00u) al[idx0 + 1] = (uint8_t)b1;
+            if (mask & 0x00FF0000u) al[idx0 + 2] = (uint8_t)b2;
+            if (mask & 0xFF000000u) al[idx0 + 3] = (uint8_t)b3;
+        }
+        carry = (carry + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63)) & 255u;
+        y = ny; st = nst;
     }
 }
 
