@@ -947,7 +947,7 @@ __device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-
 __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                        TileSel sel, const uint32_t *__restrict__ resid,
                                                        uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags) {
-    __shared__ uint32_t seam[RB_MAXW];
+    extern __shared__ uint32_t seam[];  // one row of the widest tile of the launch (bottom row of the band above)
     const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
     const DecTile *d = info + j;
     const uint32_t type = d->type;
@@ -969,15 +969,22 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
     for (uint32_t yb = 0; yb < t.h; yb += 64) {
         const uint32_t y = yb + lane;
         const bool active = y < t.h;
-        // (a lane reads up to 63 words before and 70 after its row: inside the tile's words, or the slack of the buffer; never used)
+        // (a lane reads up to 63 words before and ~100 after its row: inside the tile's words, or the >= 192 words of slack behind them; never used)
         const uint32_t *rsrow = rs + (active ? (uint64_t)y * t.w : (uint64_t)lane);
         uint8_t *drow = dst + (uint64_t)(active ? y : 0) * bpr;
         const uint32_t S = t.w + 63;
         uint32_t prev = 0, U = 0, ev = 0;
-        u32x4_a4r nxt = *reinterpret_cast<const u32x4_a4r *>(rsrow - (int32_t)lane);
-        for (uint32_t s = 0; s < S; s += 4) {
-            const u32x4_a4r cur4 = nxt;
-            nxt = *reinterpret_cast<const u32x4_a4r *>(rsrow + ((int32_t)s + 4 - (int32_t)lane));
+        // residual words are read four groups (16 steps) ahead: loads and stores retire in issue order on this ISA, so the
+        // distance is also what a store gets to complete before the wave next waits on a load
+        u32x4_a4r ring[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ring[q] = *reinterpret_cast<const u32x4_a4r *>(rsrow + (4 * q - (int32_t)lane));
+        for (uint32_t s0 = 0; s0 < S; s0 += 16) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t s = s0 + 4 * q;
+            const u32x4_a4r cur4 = ring[q];
+            ring[q] = *reinterpret_cast<const u32x4_a4r *>(rsrow + ((int32_t)s + 16 - (int32_t)lane));
             if (yb > 0 && (s & 63u) == 0 && (int32_t)s < w) ev = (int32_t)(s + lane) < w ? seam[s + lane] : 0u;  // next 64 columns of the row above the band
             const uint32_t rwv[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
             uint32_t o[4];
@@ -1016,6 +1023,7 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
 #pragma unroll
                 for (int k = 0; k < 4; k++) { const int32_t x = x0 + k; if (x >= 0 && x < w) *reinterpret_cast<uint32_t *>(drow + 4ll * x) = o[k]; }
             }
+          }
         }
     }
 }
@@ -1119,7 +1127,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (wide) k_dec_resid<4, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
         else k_dec_resid<4, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, getenv("XPNG_DBG_NOSTORE") ? 1u : 0u);
+        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<<<total, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, getenv("XPNG_DBG_NOSTORE") ? 1u : 0u);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
