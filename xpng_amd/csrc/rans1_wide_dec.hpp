@@ -186,17 +186,19 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
         const uint32_t slot_ = slo & mask;
         uint32_t sym, F, off;
         if (!BIG) {
-            const bool b2 = slot_ >= cm[4];
-            const bool b1 = slot_ >= (b2 ? cm[6] : cm[2]);
-            const uint32_t t3 = b2 ? (b1 ? cm[7] : cm[5]) : (b1 ? cm[3] : cm[1]);
+            // (selects by value through pick32: see k_rans2_dec_chain)
+            const uint32_t c1 = cm[1], c2 = cm[2], c3 = cm[3], c4 = cm[4], c5 = cm[5], c6 = cm[6], c7 = cm[7], c8 = cm[8], c9 = cm[9];
+            const bool b2 = slot_ >= c4;
+            const bool b1 = slot_ >= pick32(b2, c6, c2);
+            const uint32_t t3 = pick32(b2, pick32(b1, c7, c5), pick32(b1, c3, c1));
             const bool b0 = slot_ >= t3;
-            const bool b3 = b2 && b1 && b0 && slot_ >= cm[8];
+            const bool b3 = b2 && b1 && b0 && slot_ >= c8;
             sym = (b2 ? 4u : 0u) + (b1 ? 2u : 0u) + (b0 ? 1u : 0u) + (b3 ? 1u : 0u);
-            const uint32_t lo01 = b0 ? cm[1] : 0u, lo23 = b0 ? cm[3] : cm[2], lo45 = b0 ? cm[5] : cm[4], lo67 = b0 ? cm[7] : cm[6];
-            const uint32_t hi01 = b0 ? cm[2] : cm[1], hi23 = b0 ? cm[4] : cm[3], hi45 = b0 ? cm[6] : cm[5], hi67 = b0 ? cm[8] : cm[7];
-            const uint32_t lo03 = b1 ? lo23 : lo01, lo47 = b1 ? lo67 : lo45, hi03 = b1 ? hi23 : hi01, hi47 = b1 ? hi67 : hi45;
-            uint32_t cum = b2 ? lo47 : lo03, nxt = b2 ? hi47 : hi03;
-            cum = b3 ? cm[8] : cum; nxt = b3 ? cm[9] : nxt;
+            const uint32_t lo01 = pick32(b0, c1, 0u), lo23 = pick32(b0, c3, c2), lo45 = pick32(b0, c5, c4), lo67 = pick32(b0, c7, c6);
+            const uint32_t hi01 = pick32(b0, c2, c1), hi23 = pick32(b0, c4, c3), hi45 = pick32(b0, c6, c5), hi67 = pick32(b0, c8, c7);
+            const uint32_t lo03 = pick32(b1, lo23, lo01), lo47 = pick32(b1, lo67, lo45), hi03 = pick32(b1, hi23, hi01), hi47 = pick32(b1, hi67, hi45);
+            uint32_t cum = pick32(b2, lo47, lo03), nxt = pick32(b2, hi47, hi03);
+            cum = pick32(b3, c8, cum); nxt = pick32(b3, c9, nxt);
             F = nxt - cum; off = slot_ - cum;
         } else {
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot_ >> csh));
