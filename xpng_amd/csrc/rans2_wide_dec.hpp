@@ -188,7 +188,10 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     typedef WdLayout<BIG> L;
     constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, WD_RING = L::RING, KIND = BIG ? 2 : 1;
-    constexpr uint32_t TSTRIDE = TAB + 4;  // LDS stride: +1 bank per table, the lanes mostly look up the same symbol
+    // LDS copy of a stream's tables: the small layout is searched in registers, so only its fc[] dwords come in (the coarse
+    // bytes stay in HBM): LDS per wave is what limits how many chains of a pipelined batch are resident at once
+    constexpr uint32_t LTAB = BIG ? TAB : L::CO_OFF;
+    constexpr uint32_t TSTRIDE = LTAB + 4;  // LDS stride: +1 bank per table, the lanes mostly look up the same symbol
     constexpr uint32_t PER = WD_RING / 8;      // words one lane requests per boundary (the pair: a quarter of the ring)
     constexpr uint32_t RSTRIDE = 4 * WD_RING + 4;  // per stream: [mirror of the last ring word][WD_RING words]
     constexpr uint32_t WD_STREAMS = STREAMS;
@@ -205,12 +208,12 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         uint32_t *dst = reinterpret_cast<uint32_t *>(ltab + ts * TSTRIDE);
         if (jj >= total || sgpr(wdec[(uint64_t)jj * 10 + c].kind) != KIND) {
             // no chain in this slot: its lanes idle through the loop, but their table lookups must still terminate
-            for (uint32_t i = lane; i < TAB / 4; i += 64) dst[i] = i <= L::FCN ? 0xFFFFu : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
+            for (uint32_t i = lane; i < LTAB / 4; i += 64) dst[i] = i <= L::FCN ? 0xFFFFu : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
             continue;
         }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dtab + ((uint64_t)jj * 10 + c) * WD_TAB_MAX);
 #pragma unroll 4
-        for (uint32_t i = lane; i < TAB / 4; i += 64) dst[i] = src[i];
+        for (uint32_t i = lane; i < LTAB / 4; i += 64) dst[i] = src[i];
     }
     __syncthreads();
     const WDec *wd = wdec + (uint64_t)(live ? j : 0) * 10 + c;
