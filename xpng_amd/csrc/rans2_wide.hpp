@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                      WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
     constexpr uint32_t TPW = BIG ? 16 : 32;       // tiles (streams) per wave
-    constexpr uint32_t TAB = BIG ? 4096 : 256;    // bytes of one encoder table
+    constexpr uint32_t TAB = BIG ? 4096 : 144;    // bytes of one encoder table in LDS (a context stream has the nine symbols nl = 0..8)
     constexpr uint32_t TSTRIDE = TAB + 16;        // +4 banks per table: lanes mostly look up the same symbol
     constexpr uint32_t SH = BIG ? 1 : 0;          // byte phase of the symbols inside 16-byte chunks (alpha symbol of pixel i is plane byte i)
     constexpr int PB = BIG ? 15 : 12;
