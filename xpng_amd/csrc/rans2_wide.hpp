@@ -23,6 +23,10 @@ struct WPrep {
     uint64_t st[2];             // final states
 };
 __device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 + c * 256 : 0; }
+// Compact form of an alpha table (streams that use at most WTC_CAP of the 256 symbols, i.e. nearly all): a symbol -> rank
+// byte map followed by the entries of the used symbols in symbol order.  1 KB instead of 4 KB of LDS per resident stream:
+// the LDS a chain wave holds for its whole life is what limits how many chains of a pipelined batch run at once.
+constexpr uint32_t WTC_CAP = 48, WTC_BYTES = 256 + WTC_CAP * 16;
 
 // streams [c_first, c_first + c_count) of every tile (the alpha streams, c = 9, are prepared and chained while the stream-
 // formation kernel is still producing the context streams: they only need the transform's alpha plane)
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                    uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
-                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF) {
+                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF, uint8_t *__restrict__ wtabc) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
@@ -63,6 +67,20 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     EncSym *gt = reinterpret_cast<EncSym *>(wtab + (uint64_t)tile * WTAB_TILE_BYTES + wtab_off(c));
     uint16_t *gF = wF + ((uint64_t)tile * 10 + c) * 256;
     for (uint32_t i = lane; i < N; i += 64) { gt[i] = tab[i]; gF[i] = (uint16_t)hist[i]; }
+    if (c == 9 && distinct <= WTC_CAP) {  // compact table: rank of symbol i = used symbols below it
+        uint8_t *gm = wtabc + (uint64_t)tile * WTC_BYTES;
+        EncSym *ge = reinterpret_cast<EncSym *>(gm + 256);
+        const uint32_t b = lane * 4;
+        uint32_t used[4], cntl = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { used[q] = (b + q < N && hist[b + q] != 0) ? 1u : 0u; cntl += used[q]; }
+        uint32_t r = wave_scan_incl(cntl) - cntl, pk = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (used[q]) { pk |= r << (8 * q); ge[r] = tab[b + q]; r++; }
+        }
+        reinterpret_cast<uint32_t *>(gm)[lane] = pk;  // unused symbols map to rank 0 (never looked up by an active step)
+    }
     if (lane == 0) *p = WPrep{1, N, distinct, 0, {0, 0}};
 }
 
@@ -79,9 +97,12 @@ template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
+                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab,
+                                                     const uint8_t *__restrict__ wtabc) {
     constexpr uint32_t TPW = BIG ? 16 : 32;       // tiles (streams) per wave
-    constexpr uint32_t TAB = BIG ? 4096 : 144;    // bytes of one encoder table in LDS (a context stream has the nine symbols nl = 0..8)
+    // bytes of one encoder table in LDS: alpha = the compact form (a stream with more than WTC_CAP used symbols reads its
+    // entries from the full table in HBM instead); a context stream has the nine symbols nl = 0..8
+    constexpr uint32_t TAB = BIG ? WTC_BYTES : 144;
     constexpr uint32_t TSTRIDE = TAB + 16;        // +4 banks per table: lanes mostly look up the same symbol
     constexpr uint32_t SH = BIG ? 1 : 0;          // byte phase of the symbols inside 16-byte chunks (alpha symbol of pixel i is plane byte i)
     constexpr int PB = BIG ? 15 : 12;
@@ -95,9 +116,10 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     for (uint32_t ts = 0; ts < TPW; ts++) {
         const uint32_t jj = grp * TPW + ts;
         if (jj >= total) break;
-        const uint4 *src = reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES + wtab_off(c));
+        const uint4 *src = BIG ? reinterpret_cast<const uint4 *>(wtabc + (uint64_t)vtile(sel, jj) * WTC_BYTES)
+                               : reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES + wtab_off(c));
         uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * TSTRIDE);
-        for (uint32_t i = lane; i < TAB / 16; i += 64) dst[i] = src[i];
+        for (uint32_t i = lane; i < TAB / 16; i += 64) dst[i] = src[i];  // (a stream without a compact table copies bytes nobody reads)
     }
     __syncthreads();
     const uint32_t tile = vtile(sel, live ? j : 0);
@@ -136,20 +158,46 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         sy0 = __builtin_amdgcn_perm(d1, d0, selb);
         sy1 = __builtin_amdgcn_perm(d3, d2, selb);
     };
+    // BIG: the 8 table entries of a block are fetched at its boundary, from the compact table in LDS (symbol -> rank byte ->
+    // entry) or, for a stream with more than WTC_CAP used symbols, from its full table in HBM; no table access inside a block
+    const bool cmp = BIG && live && p->distinct <= WTC_CAP;
+    const uint8_t *lmap = ltab + (k < TPW ? k : 0) * TSTRIDE;
+    const EncSym *lent = reinterpret_cast<const EncSym *>(lmap + 256);
+    const EncSym *gfull = reinterpret_cast<const EncSym *>(wtab + (uint64_t)tile * WTAB_TILE_BYTES);
+    EncSym E[8];
+    auto entries = [&]() __attribute__((always_inline)) {
+        uint32_t sy[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sy[u] = ((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u;
+        if (cmp) {
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) r[u] = lmap[sy[u]];
+#pragma unroll
+            for (int u = 0; u < 8; u++) E[u] = lent[r[u]];
+        } else if (live) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) E[u] = gfull[sy[u]];
+        }
+    };
     request(0); land(); request(1);
     constexpr uint32_t cmpl_base = 1u << PB;
     constexpr int thr_shift = 31 - PB;
     uint64_t s = RANS_L;
     uint32_t cnt = 0;
-    EncSym e = tab[sy0 & 255u];
+    EncSym e = EncSym{0, 0, 0, 0};
+    if (BIG) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) E[u] = EncSym{0, 0, 1u, 0};
+        entries();
+    } else e = tab[sy0 & 255u];
     for (uint32_t kb = 0; kb < T; kb += 8) {
         uint32_t cb = 0;  // words the pair has staged in this block
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            // table entry of the NEXT step (its LDS latency hides under this step's arithmetic); the first symbol of the next
-            // block is not in registers yet, that entry is read after the boundary
             EncSym en = e;
-            if (u < 7) en = tab[((u + 1 < 4 ? sy0 : sy1) >> (8 * ((u + 1) & 3))) & 255u];
+            if (BIG) e = E[u];
+            else if (u < 7) en = tab[((u + 1 < 4 ? sy0 : sy1) >> (8 * ((u + 1) & 3))) & 255u];  // entry of the NEXT step, under this step's arithmetic
             const bool act = kb + (uint32_t)u < mysteps;
             const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
             const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
@@ -162,7 +210,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
                 const uint64_t q = __umul64hi(s, rcp) >> rsh;
                 s += e.bias + q * (uint64_t)(cmpl_base - freq);
             }
-            e = en;
+            if (!BIG) e = en;
         }
         // ---- boundary: staged words out (lane `par` stores words 8 par .. 8 par + 7), next block's symbols land
         if (cb > 8 * par) {
@@ -176,7 +224,8 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         cnt += cb;
         land();
         request((kb >> 3) + 2);
-        e = tab[sy0 & 255u];
+        if (BIG) entries();
+        else e = tab[sy0 & 255u];
     }
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
 }

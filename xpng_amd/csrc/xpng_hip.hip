@@ -108,7 +108,7 @@ struct xpnghip_ctx {
     std::vector<const void *> h_dec_in_ptrs;
     std::vector<void *> h_dec_out_ptrs;
     WPrep *d_wprep = nullptr;   // wide entropy stage: per (tile, stream) record, encoder tables, normalised frequencies
-    uint8_t *d_wtab = nullptr;
+    uint8_t *d_wtab = nullptr, *d_wtabc = nullptr;
     uint16_t *d_wF = nullptr;
     // mode 2 (RGB slow level): allocated on first use
     uint8_t *d_scratch2 = nullptr;
@@ -135,7 +135,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
-                    c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
+                    c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
     if (c->ev_enc_fork) (void)hipEventDestroy(c->ev_enc_fork);
@@ -191,6 +191,7 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
     ALLOC(c->d_dbg, VN * 10 * 8 * 8 * 2);
     ALLOC(c->d_wprep, VN * 10 * sizeof(WPrep));
     ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096);
+    ALLOC(c->d_wtabc, VN * WTC_BYTES + 4096);
     ALLOC(c->d_wF, VN * 10 * 512);
     ALLOC(c->d_blob_len, (uint64_t)batch * 8);
     ALLOC(c->d_status, 64);
@@ -329,8 +330,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         }
         HIPCHK(hipEventRecord(c->ev_enc_fork, s));
         HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
-        k_rans2_prep<<<total, 64, 0, c->enc_side>>>(c->d_tiles, sel, 9, 1, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        k_rans2_chain2<true><<<(total + 15) / 16, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        k_rans2_prep<<<total, 64, 0, c->enc_side>>>(c->d_tiles, sel, 9, 1, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
+        k_rans2_chain2<true><<<(total + 15) / 16, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         HIPCHK(hipEventRecord(c->ev_enc_join, c->enc_side));
     }
     if ((uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
@@ -339,8 +340,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
+        k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         if (alpha_early) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
         k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
