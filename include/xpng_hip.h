@@ -68,6 +68,9 @@ int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int 
  * A context owns the tile table (libxpng.c:51-83) and every intermediate buffer for one raster
  * geometry on one device, so the hot path itself performs no allocation and no host sync except the
  * final 8-byte length read-back.  `stream` is a hipStream_t passed as void* (NULL = the context's own).
+ * A context is a single-queue object: the calls made on one context must be ordered (issue them on one stream).
+ * Its buffers are reused from call to call, and the decode workspace lives inside the encode stream scratch.
+ * Use one context per pipeline slot to overlap work.
  */
 typedef struct xpnghip_ctx xpnghip_ctx;
 
