@@ -17,6 +17,7 @@
 #pragma once
 #include "common.hpp"
 
+#include <type_traits>
 namespace xpng {
 
 struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_prep
@@ -40,6 +41,13 @@ template <bool BIG> struct WdLayout {
     static constexpr uint32_t CBITS = BIG ? 10 : 8, FCN = BIG ? 256 : 16, RING = BIG ? 64 : 32;
     static constexpr uint32_t REGN = 9;  // small layout: at most 9 symbols (nl = 0..8), searched in registers
     static constexpr uint32_t CO_OFF = 4 * (FCN + 1), TAB = CO_OFF + (1u << CBITS);
+};
+// Alpha streams of mode 1 (pb 15, up to 256 symbols) use a denser form of the big layout: 16-bit cumulative counts
+// cum[0 .. N] (cum[N] = 2^pb; entries behind it 0xFFFF, which stops any scan), F = cum[sym + 1] - cum[sym], and 2^9 coarse
+// bytes (64-slot buckets): 1 KB instead of 2 KB of LDS per resident stream, the largest LDS holder of a pipelined batch.
+struct WdLayoutA {
+    static constexpr uint32_t CBITS = 9, FCN = 256, RING = 64, REGN = 9;
+    static constexpr uint32_t CO_OFF = 2 * (FCN + 2), TAB = CO_OFF + (1u << CBITS);
 };
 constexpr uint32_t WD_TAB_MAX = WdLayout<true>::TAB;  // HBM stride of one stream's tables
 
@@ -134,10 +142,15 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
     __syncthreads();
     uint8_t *gt = dtab + ((uint64_t)j * 10 + c) * WD_TAB_MAX;
     const bool small = c < 9 && pb <= 12 && N <= WdLayout<false>::REGN;
-    const uint32_t fcn = small ? WdLayout<false>::FCN : WdLayout<true>::FCN, co_off = 4 * (fcn + 1);
-    const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayout<true>::CBITS;
-    uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
-    for (uint32_t i = lane; i <= fcn; i += 64) gfc[i] = i < N ? fc[i] : 0xFFFFu;
+    const uint32_t co_off = small ? WdLayout<false>::CO_OFF : WdLayoutA::CO_OFF;
+    const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayoutA::CBITS;
+    if (small) {
+        uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
+        for (uint32_t i = lane; i <= WdLayout<false>::FCN; i += 64) gfc[i] = i < N ? fc[i] : 0xFFFFu;
+    } else {
+        uint16_t *gcu = reinterpret_cast<uint16_t *>(gt);
+        for (uint32_t i = lane; i <= WdLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < N ? fc[i] >> 16 : (i == N ? 1u << pb : 0xFFFFu));
+    }
     {   // coarse slot -> symbol
         const uint32_t sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
         for (uint32_t g0 = lane * 4; g0 < entries; g0 += 256) {
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
 
 typedef __attribute__((address_space(3))) uint8_t lds8;
 typedef __attribute__((address_space(3))) uint32_t lds32;
+typedef __attribute__((address_space(3))) uint16_t lds16;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds128;
 
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ ctxsym,
                                                         uint8_t *__restrict__ asym) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
-    typedef WdLayout<BIG> L;
+    typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
     constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, WD_RING = L::RING, KIND = BIG ? 2 : 1;
     // LDS copy of a stream's tables: the small layout is searched in registers, so only its fc[] dwords come in (the coarse
     // bytes stay in HBM): LDS per wave is what limits how many chains of a pipelined batch are resident at once
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         uint32_t *dst = reinterpret_cast<uint32_t *>(ltab + ts * TSTRIDE);
         if (jj >= total || sgpr(wdec[(uint64_t)jj * 10 + c].kind) != KIND) {
             // no chain in this slot: its lanes idle through the loop, but their table lookups must still terminate
-            for (uint32_t i = lane; i < LTAB / 4; i += 64) dst[i] = i <= L::FCN ? 0xFFFFu : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
+            for (uint32_t i = lane; i < LTAB / 4; i += 64) dst[i] = i < L::CO_OFF / 4 ? (BIG ? 0xFFFFFFFFu : 0xFFFFu) : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
             continue;
         }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dtab + ((uint64_t)jj * 10 + c) * WD_TAB_MAX);
@@ -255,8 +269,13 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     uint32_t hs0 = 0, hs1 = 0, hC0 = 0, hF0 = 0x10000u, hC1 = 0, hF1 = 0;  // idle lanes: "always hit" (their step is the identity anyway)
     if (HOT && live) {
         hs0 = wd->hot0; hs1 = wd->hot1;
-        const uint32_t e0 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs0), e1 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs1);
-        hF0 = e0 & 0xFFFFu; hC0 = e0 >> 16; hF1 = e1 & 0xFFFFu; hC1 = e1 >> 16;
+        if (BIG) {
+            hC0 = *(const lds16 *)(uintptr_t)(a_fc + 2 * hs0); hF0 = *(const lds16 *)(uintptr_t)(a_fc + 2 * hs0 + 2) - hC0;
+            hC1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * hs1); hF1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * hs1 + 2) - hC1;
+        } else {
+            const uint32_t e0 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs0), e1 = *(const lds32 *)(uintptr_t)(a_fc + 4 * hs1);
+            hF0 = e0 & 0xFFFFu; hC0 = e0 >> 16; hF1 = e1 & 0xFFFFu; hC1 = e1 >> 16;
+        }
     }
     // Small layout (nl-context streams, at most 9 symbols): the cumulative counts c1..c9 live in registers and a step finds
     // its symbol by a binary search over them, instead of two dependent LDS reads and a data-dependent scan that the whole
@@ -296,9 +315,9 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             F = nxt - cum; off = slot - cum;
         } else {
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
-            uint32_t e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym);
-            while (slot - (e >> 16) >= (e & 0xFFFFu)) { sym++; e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym); }  // entries >= N stop it (F = 0xFFFF)
-            F = e & 0xFFFFu; off = slot - (e >> 16);
+            uint32_t c0 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym), c1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym + 2);
+            while (slot >= c1) { sym++; c0 = c1; c1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym + 2); }  // entries behind cum[N] stop it (0xFFFF)
+            F = c1 - c0; off = slot - c0;
         }
         if (!act) { F = ident; off = slot; }
         const uint32_t qlo = __builtin_amdgcn_alignbit(shi, slo, pb), qhi = shi >> pb;  // s >> pb
