@@ -457,3 +457,30 @@ def test_mode2_large_batch_takes_the_wide_path_and_matches(gpu, po):
     for i in range(B):
         assert np.array_equal(d_o[i][: w * h * 3].cpu().numpy().reshape(h, w, 3), base[i % 3]), i
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_syms", [3, 30, 47, 49, 64, 200])
+def test_alpha_alphabet_sizes_on_the_wide_path(gpu, po, monkeypatch, k_syms):
+    """The wide alpha encode chain keeps a compact table (symbol -> rank map + used entries) in LDS when at most 48 of the
+    256 alpha symbols occur and reads the full table from HBM otherwise; the wide alpha decode chain uses 16-bit cumulative
+    tables.  Alphabets on both sides of that boundary, bytes against the oracle, then the round trip."""
+    monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    from xpng_amd.synth import synth_raster
+    rng = np.random.default_rng(k_syms)
+    W, H = 600, 520
+    raster = synth_raster("photo", W, H, True, seed=5).copy()
+    steps = rng.choice(np.arange(1, 256), size=k_syms - 1, replace=False)          # alpha deltas in use (plus 0)
+    d = np.where(rng.random((H, W)) < 0.7, 0, rng.choice(steps, size=(H, W))).astype(np.int64)
+    a = (np.cumsum(d, axis=1) + 1) & 255
+    raster[..., 3] = a.astype(np.uint8)
+    raster[raster[..., 3] == 0] = 0
+    want = po.encode_image(1, raster)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "a.xpng")
+        gpu.store(1, raster, p)
+        data = open(p, "rb").read()
+        assert data == want, k_syms
+        back = gpu.load(p)
+    assert np.array_equal(back, np.ascontiguousarray(po.normalize_rgba(raster)))
