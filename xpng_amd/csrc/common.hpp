@@ -37,7 +37,7 @@ __host__ __device__ inline uint32_t imglin(const TileSel &s, uint32_t vt) { cons
 // so that host and device agree without a table.  Capacities are worst cases:
 //   context stream  : <= n-1 symbols, 1 B each
 //   k bit stream    : 8*pxsz bits + <= 24 bits/pixel
-//   rANS v2 block   : 12 B header + ceil(n*pb/32) words + 16 B states + table (<= 256*16 bits)
+//   rANS v2 block   : 12 B header + ceil(m*pb/32) words + 16 B states + table (<= 256*16 bits), m = symbols of the stream
 __host__ __device__ inline uint64_t rup(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 __host__ __device__ inline uint64_t ctx_cap(uint32_t n) { return rup((uint64_t)n + 64, 256); }
 __host__ __device__ inline uint64_t kw_cap(uint32_t n) { return rup(3ull * n + 64, 256); }
@@ -45,10 +45,20 @@ __host__ __device__ inline uint64_t ctxblk_cap(uint32_t n) { return rup(3ull * n
 __host__ __device__ inline uint64_t alphablk_cap(uint32_t n) { return rup(2ull * n + 1280, 256); }
 __host__ __device__ inline uint64_t off_ctx(uint32_t n, int c) { return (uint64_t)c * ctx_cap(n); }
 __host__ __device__ inline uint64_t off_kw(uint32_t n) { return 9 * ctx_cap(n); }
-__host__ __device__ inline uint64_t off_blk(uint32_t n, int c) {  // c = 0..8 context blocks, 9 = alpha
-    return off_kw(n) + kw_cap(n) + (uint64_t)c * ctxblk_cap(n);
+// Block slots: the alpha block first (its place must not depend on the context stream lengths: the alpha chains start while
+// the stream kernel is still running), then the nine context blocks back to back, each sized by ITS stream's length cn[c]
+// (known once k_m1_streams has run) instead of nine slots of the worst case n: the streams share n - 1 symbols, so the nine
+// take <= 1.5 n + 9 * 383 bytes together, not 13.5 n.
+__host__ __device__ inline uint64_t off_blk(uint32_t n, const uint32_t *cn, int c) {  // c = 0..8 context blocks, 9 = alpha
+    uint64_t o = off_kw(n) + kw_cap(n);
+    if (c == 9) return o;
+    o += alphablk_cap(n);
+    for (int i = 0; i < c; i++) o += ctxblk_cap(cn[i]);
+    return o;
 }
-__host__ __device__ inline uint64_t tile_scratch_bytes(uint32_t n) { return off_blk(n, 9) + alphablk_cap(n); }
+__host__ __device__ inline uint64_t tile_scratch_bytes(uint32_t n) {
+    return off_kw(n) + kw_cap(n) + alphablk_cap(n) + rup(3ull * n / 2 + 9 * 383, 256);
+}
 
 // ---- integer helpers shared by encode and decode (reference libxpng.c:19-30) ----------------------
 __device__ __forceinline__ int bit_width(uint32_t v) { return v ? 32 - __clz((int)v) : 0; }  // numBit

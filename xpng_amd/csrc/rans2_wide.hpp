@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     int pb;
     if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
-    uint32_t *out = reinterpret_cast<uint32_t *>(sc + off_blk(t.n, (int)c));
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c));
     WPrep *p = prep + (uint64_t)tile * 10 + c;
     if (n == 0) {  // libxpng.c:313
         if (lane == 0) { out[0] = 4; blk_sz[(uint64_t)tile * 10 + c] = 4; *p = WPrep{0, 0, 0, 4, {0, 0}}; }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(T, o); T = v > T ? v : T; }
     T = sgpr((T + 7) & ~7u);
     const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
-    uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t->n, (int)c)) + 3;
+    uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t->n, ctx_n + (uint64_t)tile * 9, (int)c)) + 3;
     uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
     // symbols of block b (pair symbols 16b .. 16b+15) = bytes [16b + SH, 16b + SH + 16) of `in`
     uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;  // in flight: the block after the current one
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void k_rans2_finish(const TileDesc *__restrict_
     int pb;
     if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; pb = 15; }
-    uint8_t *out8 = sc + off_blk(t.n, (int)c);
+    uint8_t *out8 = sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c);
     uint32_t *out = reinterpret_cast<uint32_t *>(out8);
     const uint16_t *F16 = wF + ((uint64_t)tile * 10 + c) * 256;
     const uint32_t N = p.N, distinct = p.distinct, rawBits = (uint32_t)bit_width(N - 1);

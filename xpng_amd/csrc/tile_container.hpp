@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict_
     int pb;
     if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
-    const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, (int)c), hist, cum, tab,
+    const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c), hist, cum, tab,
                                            dbg ? dbg + ((uint64_t)tile * 10 + c) * 8 : nullptr);
     if ((threadIdx.x & 63) == 0) blk_sz[(uint64_t)tile * 10 + c] = sz;
 }
@@ -97,6 +97,7 @@ __device__ __forceinline__ void block_copy(uint8_t *dst, const uint8_t *src, uin
 __global__ __launch_bounds__(256) void k_tile_gather(const uint8_t *const *__restrict__ rasters, uint64_t bpr, int pxsz,
                                                      const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
                                                      const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ k_n,
+                                                     const uint32_t *__restrict__ ctx_n,
                                                      const uint32_t *__restrict__ blk_sz, const uint32_t *__restrict__ tile_hdr,
                                                      const uint64_t *__restrict__ off, uint8_t *const *__restrict__ blobs) {
     const uint32_t j = blockIdx.x, tile = vtile(sel, j);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_tile_gather(const uint8_t *const *__res
     uint64_t o = 4 + ksz;
     for (uint32_t c = 0; c < spt; c++) {
         const uint32_t sz = blk_sz[(uint64_t)tile * 10 + c];
-        block_copy(dst + o, sc + off_blk(t.n, (int)c), sz);
+        block_copy(dst + o, sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c), sz);
         o += sz;
     }
 }

@@ -347,7 +347,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
     k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
-    k_tile_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
+    k_tile_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_ctx_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
     return 0;
@@ -661,8 +661,9 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
         src = c->d_scratch + t.sbase + off_kw(t.n); bytes = 4ull * tmp[0];
     } else if (what >= 20 && what <= 29) {
         if ((uint32_t)(what - 20) >= c->spt) return 0;
-        if (!d2h(tmp, c->d_blk_sz + tile * 10, 40)) return -1;
-        src = c->d_scratch + t.sbase + off_blk(t.n, what - 20); bytes = tmp[what - 20];
+        uint32_t cn[9];
+        if (!d2h(cn, c->d_ctx_n + tile * 9, 36) || !d2h(tmp, c->d_blk_sz + tile * 10, 40)) return -1;
+        src = c->d_scratch + t.sbase + off_blk(t.n, cn, what - 20); bytes = tmp[what - 20];
     } else if (what == 40 || what == 41) {
         src = (const uint8_t *)(c->d_dbg + ((what - 40) * c->tiles.size() * c->B + tile) * 80); bytes = 640;
     } else if (what == 30) {
