@@ -1100,7 +1100,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // Many tiles in flight: instruction issue is the bound, so the rANS chains run 32 streams to a wave (rans2_wide_dec.hpp);
     // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.
     const bool wide = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * spt > 2048 || getenv("XPNG_WIDE_RANS"));
-    constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 16;
+    constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 32;
     const uint32_t groups = (total + WD_CTX_STREAMS - 1) / WD_CTX_STREAMS, agroups = (total + WD_ALPHA_STREAMS - 1) / WD_ALPHA_STREAMS;
     if (wide) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
     // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short

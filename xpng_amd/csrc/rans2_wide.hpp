@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                      WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab,
                                                      const uint8_t *__restrict__ wtabc) {
-    constexpr uint32_t TPW = BIG ? 16 : 32;       // tiles (streams) per wave
+    constexpr uint32_t TPW = 32;                  // tiles (streams) per wave: every lane carries a state (alpha ran 16 per wave while its tables took 4 KB of LDS each)
     // bytes of one encoder table in LDS: alpha = the compact form (a stream with more than WTC_CAP used symbols reads its
     // entries from the full table in HBM instead); a context stream has the nine symbols nl = 0..8
     constexpr uint32_t TAB = BIG ? WTC_BYTES : 144;

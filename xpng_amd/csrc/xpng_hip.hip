@@ -331,7 +331,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         HIPCHK(hipEventRecord(c->ev_enc_fork, s));
         HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
         k_rans2_prep<<<total, 64, 0, c->enc_side>>>(c->d_tiles, sel, 9, 1, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        k_rans2_chain2<true><<<(total + 15) / 16, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        k_rans2_chain2<true><<<(total + 31) / 32, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         HIPCHK(hipEventRecord(c->ev_enc_join, c->enc_side));
     }
     if ((uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
