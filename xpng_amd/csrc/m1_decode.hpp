@@ -944,6 +944,7 @@ constexpr uint32_t RB_MAXW = 2048;  // seam buffer, pixels
 __device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-byte a + b (mod 256)
     return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
 }
+template <int PXSZ>
 __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                        TileSel sel, const uint32_t *__restrict__ resid,
                                                        uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags) {
@@ -953,15 +954,15 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
     const uint32_t type = d->type;
     if (type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
-    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * 4;
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
     if (type == 0) {  // raw rows (libxpng.c:846)
         const uint8_t *src = d->blob + 4;
-        const uint64_t row = (uint64_t)t.w * 4;
+        const uint64_t row = (uint64_t)t.w * PXSZ;
         for (uint64_t b = lane; b < row * t.h; b += 64) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
         return;
     }
     const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
-    const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | ((kw0 & 255u) << 24);
+    const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | (PXSZ == 4 ? (kw0 & 255u) << 24 : 0u);
     const bool grad = (type >> 1) & 1;
     const uint32_t *rs = resid + t.pbase;
     const int32_t w = (int32_t)t.w;
@@ -1016,12 +1017,28 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
                 o[k] = px;
                 if (lane == 63 && on) seam[x] = px;  // (a full band: lane 63 is an existing row)
             }
-            if (dbgflags & 1) { if (lane == 0 && x0 >= 0 && x0 + 3 < w) *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]}; }
-            else if (active && x0 >= 0 && x0 + 3 < w) {
-                *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]};
-            } else if (active) {
+            if (PXSZ == 4) {
+                if (dbgflags & 1) { if (lane == 0 && x0 >= 0 && x0 + 3 < w) *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]}; }
+                else if (active && x0 >= 0 && x0 + 3 < w) {
+                    *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]};
+                } else if (active) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int32_t x = x0 + k; if (x >= 0 && x < w) *reinterpret_cast<uint32_t *>(drow + 4ll * x) = o[k]; }
+                    for (int k = 0; k < 4; k++) { const int32_t x = x0 + k; if (x >= 0 && x < w) *reinterpret_cast<uint32_t *>(drow + 4ll * x) = o[k]; }
+                }
+            } else {
+                // RGB: the (marker) top byte of a pixel word is dropped; four pixels are 12 consecutive bytes at any alignment
+                typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+                const uint32_t p0 = o[0] & 0xFFFFFFu, p1 = o[1] & 0xFFFFFFu, p2 = o[2] & 0xFFFFFFu, p3 = o[3] & 0xFFFFFFu;
+                if (active && x0 >= 0 && x0 + 3 < w) {
+                    *reinterpret_cast<u32x3_a1 *>(drow + 3ll * x0) = u32x3_a1{p0 | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+                } else if (active) {
+                    const uint32_t pk[4] = {p0, p1, p2, p3};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int32_t x = x0 + k;
+                        if (x >= 0 && x < w) { uint8_t *q = drow + 3ll * x; q[0] = (uint8_t)pk[k]; q[1] = (uint8_t)(pk[k] >> 8); q[2] = (uint8_t)(pk[k] >> 16); }
+                    }
+                }
             }
           }
         }
@@ -1127,13 +1144,14 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (wide) k_dec_resid<4, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
         else k_dec_resid<4, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<<<total, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, getenv("XPNG_DBG_NOSTORE") ? 1u : 0u);
+        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<4><<<total, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, getenv("XPNG_DBG_NOSTORE") ? 1u : 0u);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
         if (wide) k_dec_resid<3, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
         else k_dec_resid<3, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<3><<<total, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u);
+        else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }
     if (hipGetLastError() != hipSuccess) return bad("decode kernel launch failed");
