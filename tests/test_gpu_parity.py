@@ -323,15 +323,18 @@ def test_batch_kernels_forced_on_small_inputs(gpu, manifest, po, tmp_path, monke
     assert np.array_equal(gpu.load(str(p)), raster)
 
 
-def test_large_batch_takes_the_wide_path_and_matches(gpu, po):
-    """A batch big enough to select the wide kernels by itself (tiles x streams > 2048)."""
+@pytest.mark.parametrize("alpha", [True, False])
+def test_large_batch_takes_the_wide_path_and_matches(gpu, po, alpha):
+    """A batch big enough to select the wide kernels by itself (tiles x streams > 2048); RGBA and RGB (the one-wave-per-tile
+    band reconstruction writes 16-byte and 12-byte pixel groups respectively)."""
     import torch
     from xpng_amd.api import walk_tile_offsets
     from xpng_amd.synth import synth_raster
-    W, H, B = 1800, 1500, 18   # 12 tiles x 10 streams x 18 images = 2160 chains
-    base = [synth_raster(k, W, H, True, seed=s + 1) for s, k in enumerate(("photo", "noise", "photo"))]
-    ctx = gpu.Context(W, H, 4, batch=B)
-    assert ctx.n_tiles * 10 * B > 2048
+    W, H, B = 1800, 1500, 18 if alpha else 21   # 12 tiles x 10 (9) streams x B images > 2048 chains
+    ch = 4 if alpha else 3
+    base = [synth_raster(k, W, H, alpha, seed=s + 1) for s, k in enumerate(("photo", "noise", "photo"))]
+    ctx = gpu.Context(W, H, ch, batch=B)
+    assert ctx.n_tiles * (10 if alpha else 9) * B > 2048
     d_r = [torch.from_numpy(base[i % 3]).cuda() for i in range(B)]
     d_b = [torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
     lens = ctx.encode_device_batch(1, [t.data_ptr() for t in d_r], [t.data_ptr() for t in d_b])
@@ -341,12 +344,13 @@ def test_large_batch_takes_the_wide_path_and_matches(gpu, po):
         blob = d_b[i][:lens[i]].cpu().numpy().tobytes()
         assert blob == want[i % 3], i
         offs.append(walk_tile_offsets(blob, ctx.n_tiles)[0])
-    d_o = [torch.zeros(W * H * 4 + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    d_o = [torch.full((W * H * ch + 64,), 0xA5, dtype=torch.uint8, device="cuda") for _ in range(B)]
     ctx.decode_device_batch(1, [t.data_ptr() for t in d_b], lens, offs, [t.data_ptr() for t in d_o])
     torch.cuda.synchronize()
     assert ctx.decode_status() == 0
     for i in range(B):
-        assert np.array_equal(d_o[i][: W * H * 4].cpu().numpy().reshape(H, W, 4), base[i % 3]), i
+        assert np.array_equal(d_o[i][: W * H * ch].cpu().numpy().reshape(H, W, ch), base[i % 3]), i
+        assert bool((d_o[i][W * H * ch:] == 0xA5).all()), i   # nothing written behind the raster
     ctx.close()
 
 
