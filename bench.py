@@ -121,7 +121,7 @@ def main():
 
     import xpng_amd
     from xpng_amd.api import walk_tile_offsets
-    from xpng_amd.shard import band_rows, gather_blobs_packed, image_from_packs, tile_table, weighted_tile_ranges
+    from xpng_amd.shard import band_rows, exchange_blobs_round_robin, image_from_round_robin, tile_table, weighted_tile_ranges
     from xpng_amd.synth import seven_header, synth_raster_torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,19 +215,21 @@ def main():
     len_table = [None]
 
     def exchange(bufs=None, scratch=None):
-        # the one exchange of the path: every rank packs its B blobs and sends ONE message to rank 0 (RCCL send/recv, 7 links
-        # into rank 0 on a node; no collective on the data path).  The first call learns the (world x B) length table; later
-        # calls pass it in, so nothing here synchronises with the host and the exchange queues behind the encode on its stream
+        # the one exchange of the path: the file of image b is assembled on rank b % world, so every rank sends each other
+        # rank ONE message per step (its tile-range blobs of that rank's images, packed): 56 messages over 56 directed xGMI
+        # links on a node instead of 7 converging on rank 0.  RCCL send/recv, no collective on the data path.  The first call
+        # learns the (world x B) length table; later calls pass it in, so nothing here synchronises with the host and the
+        # exchange queues behind the encode on its stream
         bufs = d_blobs_all if bufs is None else bufs
         if use_host:
             bufs = [t[:lens_b[i]].cpu() for i, t in enumerate(bufs)]
-        packs, table = gather_blobs_packed(bufs, lens_b, table=len_table[0], scratch=scratch)
+        recv, table = exchange_blobs_round_robin(bufs, lens_b, table=len_table[0], scratch=scratch)
         len_table[0] = table
-        return packs, table
+        return recv, table
 
     if world > 1:
-        packs, table = exchange()
-        gathered, lens = (image_from_packs(packs, table, 0) if rank == 0 else None), [row[0] for row in table]
+        recv, table = exchange()
+        gathered, lens = (image_from_round_robin(recv, table, 0, 0) if rank == 0 else None), [row[0] for row in table]
     else:
         gathered, lens = d_blobs_all[0][:n], [n]
     if rank == 0:
@@ -327,7 +329,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' {'RGBA8' if alpha else 'RGB8'}, level -1 (FAST), tile encode + decode, rasters and blobs resident in HBM",
                        "batch": B, "pipeline_slots": P, "tiles": len(tiles), "tiles_per_rank": t1 - t0, "share_px": my_px,
-                       "parallelism": f"tile-range x{world}" + (f" + one packed send of the step's blobs per rank to rank 0 ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
+                       "parallelism": f"tile-range x{world}" + (f" + file assembly spread over the ranks (image b on rank b % {world}): one packed message per rank pair and step ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
                        "compressed_bytes": int(sum(lens)), "distinct_rasters_per_launch": B,
                        "hbm_in_use_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30, 1)},
             "verified": verified,

@@ -72,7 +72,7 @@ def _worker_batch(rank, world, port, q):
     from oracle import pyoracle as po
     from xpng_amd.shard import gather_blobs_batch, tile_table, weighted_tile_ranges
     from xpng_amd.synth import synth_raster
-    W, H, B = 1000, 900, 2
+    W, H, B = 1000, 900, 3
     tiles = tile_table(W, H)
     t0, t1 = weighted_tile_ranges(tiles, world)[rank]
     bufs, lens = [], []
@@ -86,8 +86,16 @@ def _worker_batch(rank, world, port, q):
     from xpng_amd.shard import gather_blobs_packed, image_from_packs
     packs, table2 = gather_blobs_packed(bufs, lens)
     packs3, table3 = gather_blobs_packed(bufs, lens, table=table2)
+    # destinations spread round robin over the ranks: image b is assembled on rank b % world
+    from xpng_amd.shard import exchange_blobs_round_robin, image_from_round_robin
+    recv, table4 = exchange_blobs_round_robin(bufs, lens)
+    recv5, _ = exchange_blobs_round_robin(bufs, lens, table=table4, scratch={})
+    for rv in (recv, recv5):
+        for b in range(rank, B, world):
+            whole = po.encode_tiles(1, synth_raster("photo", W, H, True, seed=b + 1))
+            assert image_from_round_robin(rv, table4, b, rank).numpy().tobytes() == whole, (rank, b)
     if rank == 0:
-        assert table2 == table and table3 == table
+        assert table2 == table and table3 == table and table4 == table
         for pk in (packs, packs3):
             assert [image_from_packs(pk, table, b).numpy().tobytes() for b in range(B)] == [o.numpy().tobytes() for o in outs]
         q.put(([o.numpy().tobytes() for o in outs], table))
@@ -95,22 +103,24 @@ def _worker_batch(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_batched_gather():
+@pytest.mark.parametrize("world", [2, 3])
+def test_batched_gathers(world):
+    """gatherv to rank 0 (per image and packed) and the round-robin exchange (image b assembled on rank b % world), 2 and 3 ranks."""
     from oracle import pyoracle as po
     from xpng_amd.synth import synth_raster
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_batch, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_batch, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, table = q.get(timeout=180)
+    got, table = q.get(timeout=240)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    for b in range(2):
+    for b in range(3):
         assert got[b] == po.encode_tiles(1, synth_raster("photo", 1000, 900, True, seed=b + 1))
-    assert len(table) == 2 and len(table[0]) == 2
+    assert len(table) == world and len(table[0]) == 3
 
 
 def test_host_tile_table_matches_oracle():

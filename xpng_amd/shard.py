@@ -221,3 +221,74 @@ def image_from_packs(packs, table, b: int):
         o = sum(table[r][:b])
         segs.append(pk[o:o + table[r][b]])
     return torch.cat(segs)
+
+
+def exchange_blobs_round_robin(locals_, lens_local, table=None, group=None, scratch=None):
+    """The final concatenation with the destinations spread over the ranks: the file of image b is assembled on rank
+    b % world.  Every rank packs, per destination, the blobs of that destination's images (one device copy) and the ranks
+    exchange ONE message per ordered pair - on an 8-GPU node 56 messages over 56 directed xGMI links, each carrying 1/8 of a
+    rank's bytes, instead of 7 messages converging on rank 0 (whose 7 inbound links would carry the whole step: the point-
+    to-point fabric has no switch to spread that).  Same byte total, no hot rank.
+
+    Returns (recv, table): recv[r] = the bytes rank r sent here (this rank's own share for r == rank), table = the
+    (world x B) length table (learnt by an all-gather when not passed in; with it nothing here synchronises with the host).
+    `image_from_round_robin(recv, table, b, rank)` cuts image b (b % world == rank) out of them."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = len(locals_)
+    dev = locals_[0].device
+    if table is None:
+        mine = torch.tensor(list(lens_local), dtype=torch.int64, device=dev)
+        flat = torch.zeros(world * B, dtype=torch.int64, device=dev)
+        if dev.type == "cuda":
+            dist.all_gather_into_tensor(flat, mine, group=group)
+        else:
+            dist.all_gather(list(flat.split(B)), mine, group=group)
+        table = [[int(v) for v in row] for row in flat.view(world, B).tolist()]
+    if [int(v) for v in table[rank]] != [int(v) for v in lens_local]:
+        raise ValueError("length table row of this rank does not match its blob lengths")
+
+    def buffer(key, nbytes):
+        if scratch is None:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        t = scratch.get(key)
+        if t is None or t.numel() != nbytes or t.device != dev:
+            t = scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return t
+
+    send_sz = [sum(table[rank][b] for b in range(d, B, world)) for d in range(world)]
+    recv_sz = [sum(table[r][b] for b in range(rank, B, world)) for r in range(world)]
+    pack = buffer("rr_pack", sum(send_sz))
+    order = [b for d in range(world) for b in range(d, B, world)]
+    if pack.numel():
+        torch.cat([locals_[b][:lens_local[b]] for b in order], out=pack)
+    send_off = [sum(send_sz[:d]) for d in range(world)]
+    recv, ops = [], []
+    for r in range(world):
+        if r == rank:
+            recv.append(pack[send_off[rank]:send_off[rank] + send_sz[rank]])
+            continue
+        buf = buffer(("rr_recv", r), recv_sz[r])
+        recv.append(buf)
+        if recv_sz[r]:
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        if send_sz[r]:
+            ops.append(dist.P2POp(dist.isend, pack[send_off[r]:send_off[r] + send_sz[r]], r, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return recv, table
+
+
+def image_from_round_robin(recv, table, b: int, rank: int):
+    """Tile blobs of image b (assembled on rank b % world == rank) in file order, out of what exchange_blobs_round_robin returned."""
+    import torch
+    world = len(table)
+    assert b % world == rank
+    segs = []
+    for r in range(world):
+        o = sum(table[r][bb] for bb in range(rank, b, world))
+        segs.append(recv[r][o:o + table[r][b]])
+    return torch.cat(segs)
