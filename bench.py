@@ -23,10 +23,10 @@ import hashlib
 import json
 import os
 
-# Every pipeline slot drives three HIP streams (main, alpha-decode side branch, alpha-encode side branch).  The HIP
-# runtime maps streams onto 4 hardware queues by default, and streams that share a queue serialise; this must be set
-# before the runtime initialises (i.e. before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Every pipeline slot drives four HIP streams (main, alpha-encode side branch, alpha-decode side branch, small-tile decode
+# tail).  The HIP runtime maps streams onto 4 hardware queues by default, and streams that share a queue serialise; this
+# must be set before the runtime initialises (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import re
 import subprocess
 import sys

@@ -2,7 +2,7 @@
 """Pipelined rate of ONE direction (encode or decode), P contexts x B distinct rasters: where does the combined rate come from?
 usage: phase_rate.py enc|dec [B=64] [P=4] [steps=24]"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

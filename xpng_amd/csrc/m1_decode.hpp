@@ -43,6 +43,8 @@ struct DecodeWs {
     uint32_t last_t0 = 0;
     hipStream_t side = nullptr;          // alpha branch runs beside the nl-context branch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side2 = nullptr;         // walk / residuals / reconstruction of the smaller tiles, beside the walk of the biggest
+    hipEvent_t ev_ctx = nullptr, ev_small = nullptr;
     DecTile *d_info = nullptr;
     uint64_t *d_off = nullptr;
     uint8_t *d_ctxsym = nullptr, *d_asym = nullptr, *d_alpha = nullptr, *d_nlseq = nullptr;
@@ -60,6 +62,9 @@ inline void decode_ws_free(DecodeWs &w) {
     void *planes[] = {w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc};
     for (void *q : planes) if (q && !w.planes_in_arena) (void)hipFree(q);
     if (w.side) (void)hipStreamDestroy(w.side);
+    if (w.side2) (void)hipStreamDestroy(w.side2);
+    if (w.ev_ctx) (void)hipEventDestroy(w.ev_ctx);
+    if (w.ev_small) (void)hipEventDestroy(w.ev_small);
     if (w.ev_fork) (void)hipEventDestroy(w.ev_fork);
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
     uint8_t *arena = w.arena;
@@ -537,14 +542,14 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 // queue at one service and land in its window at the next (the chunk starts are 16-byte aligned, k_dec_parse).
 __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
-                                                      uint8_t *__restrict__ nlseq) {
+                                                      uint8_t *__restrict__ nlseq, uint32_t j0) {
     __shared__ u32x4_t head[10 * 64];
     // window: WCH chunks of 16 B per queue; a queue is serviced every SVC-th block.  (8 chunks / every 4th block is ~8 % faster
     // alone, but 90 KB of LDS per wave instead of 50 costs the kernels beside it more than that.)
     constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;
     __shared__ uint32_t ringw[10 * WDW * 64];
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
-    const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 64 + lane;
+    const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * 64 + lane;  // work items [j0, total_tiles)
     bool live = j < total_tiles;
     const DecTile *d = info + (live ? j : 0);
     live = live && d->type != 0 && d->type != TILE_BAD;
@@ -645,11 +650,11 @@ template <int PXSZ, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict__ info,
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint8_t *__restrict__ nlseq,
-                                                    uint32_t *__restrict__ resid) {
+                                                    uint32_t *__restrict__ resid, uint32_t j0) {
     // One workgroup walks a tile in raster order, THREADS * 4 pixels per iteration; a lane owns 4 consecutive pixels: one
     // dword of the alpha plane (read one iteration ahead), up to 4 consecutive nl symbols, up to 96 bits of k, one 16-byte
     // store of residual words.  Two wave scans (coded pixels, bit lengths) and two barriers per iteration.
-    const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DecTile d = info[j];
     if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
@@ -947,9 +952,9 @@ __device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-
 template <int PXSZ>
 __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                        TileSel sel, const uint32_t *__restrict__ resid,
-                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags) {
+                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0) {
     extern __shared__ uint32_t seam[];  // one row of the widest tile of the launch (bottom row of the band above)
-    const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t j = j0 + blockIdx.x, lane = threadIdx.x & 63;
     const DecTile *d = info + j;
     const uint32_t type = d->type;
     if (type == TILE_BAD) return;
@@ -1098,7 +1103,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                             uint32_t max_w, uint32_t max_h, int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *d_blob_len,
                             uint32_t *d_status, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr,
-                            const uint32_t *d_order = nullptr) {
+                            const uint32_t *d_order = nullptr, uint32_t n_big = 0) {
     const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
@@ -1138,22 +1143,56 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
     }
-    if (wide && !getenv("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq);
+    // Two size classes: the walk's duration is the chain of the biggest tile, and the work enumeration is sorted by size, so the
+    // first n_big tiles of the order (x B images) are walked on `s` while the rest - shorter chains - are walked on a second
+    // stream, which then extracts residuals and reconstructs them while the big walk is still running; what is left behind
+    // the long walk is the residual / reconstruction work of the few big tiles only.
+    const bool band = wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON");
+    // (a third stream per context: with fewer hardware queues than the streams of all contexts in flight, streams share a queue
+    // and serialise - measured 31 -> 21 Gpx/s at 4 contexts and 16 queues - so the split is taken only when the process asked
+    // the runtime for at least 24 queues, GPU_MAX_HW_QUEUES, as bench.py does)
+    static const bool many_queues = [] { const char *q = getenv("GPU_MAX_HW_QUEUES"); return q && atoi(q) >= 24; }();
+    const bool split = band && d_order && n_big > 0 && n_big < cnt && !getenv("XPNG_NARROW_WALK") && !getenv("XPNG_NO_SPLIT") &&
+                       (many_queues || getenv("XPNG_SPLIT"));
+    const uint32_t jb = split ? n_big * B : 0;
+    const uint32_t nostore = getenv("XPNG_DBG_NOSTORE") ? 1u : 0u;
+    if (split) {
+        if (!ws.side2) {
+            if (hipStreamCreateWithFlags(&ws.side2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ws.ev_ctx, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming) != hipSuccess)
+                return bad("stream/event creation failed");
+        }
+        if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
+        k_dec_walk_wide<<<(total - jb + 63) / 64, 64, 0, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+        k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
+        if (pxsz == 4) {
+            k_dec_resid<4, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
+            k_dec_recon_band<4><<<total - jb, 64, (size_t)max_w * 4 + 256, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
+        } else {
+            k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
+            k_dec_recon_band<3><<<total - jb, 64, (size_t)max_w * 4 + 256, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
+        }
+        if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
+    } else if (wide && !getenv("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
+    const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
-        if (wide) k_dec_resid<4, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        else k_dec_resid<4, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<4><<<total, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, getenv("XPNG_DBG_NOSTORE") ? 1u : 0u);
+        if (wide) k_dec_resid<4, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        if (band) k_dec_recon_band<4><<<nt, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
-        if (wide) k_dec_resid<3, 256><<<total, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        else k_dec_resid<3, 1024><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid);
-        if (wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON")) k_dec_recon_band<3><<<total, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u);
+        if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        if (band) k_dec_recon_band<3><<<nt, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0);
         else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }
+    if (split && hipStreamWaitEvent(s, ws.ev_small, 0) != hipSuccess) return bad("join failed");
     if (hipGetLastError() != hipSuccess) return bad("decode kernel launch failed");
     return 0;
 }

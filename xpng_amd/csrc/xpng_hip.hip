@@ -109,6 +109,7 @@ struct xpnghip_ctx {
     std::vector<void *> h_dec_out_ptrs;
     WPrep *d_wprep = nullptr;   // wide entropy stage: per (tile, stream) record, encoder tables, normalised frequencies
     uint8_t *d_wtab = nullptr, *d_wtabc = nullptr;
+    uint32_t n_big = 0;
     uint16_t *d_wF = nullptr;
     // mode 2 (RGB slow level): allocated on first use
     uint8_t *d_scratch2 = nullptr;
@@ -206,6 +207,9 @@ extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t 
         for (uint64_t i = c->r0; i < c->r1; i++) ord.push_back((uint32_t)i);
         std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return c->tiles[a].n > c->tiles[b].n; });
         if (hipMemcpy(c->d_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { xpnghip_ctx_destroy(c); return fail("context setup failed"); }
+        // size class of the biggest tiles (>= 3/4 of the largest pixel count): the decode walks them beside the rest (m1_decode.hpp)
+        c->n_big = 0;
+        for (uint32_t i : ord) if ((uint64_t)c->tiles[i].n * 4 >= (uint64_t)c->tiles[ord[0]].n * 3) c->n_big++;
     }
     c->stamps = getenv("XPNG_STAMPS") != nullptr;
     if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
@@ -459,7 +463,7 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     }
     return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off,
                             (uint32_t)t0, (uint32_t)t1, c->d_dec_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr,
-                            order_for(c, (uint32_t)t0, (uint32_t)t1));
+                            order_for(c, (uint32_t)t0, (uint32_t)t1), order_for(c, (uint32_t)t0, (uint32_t)t1) ? c->n_big : 0u);
 }
 extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
                                      const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
