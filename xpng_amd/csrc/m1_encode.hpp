@@ -119,6 +119,24 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
     const int useGrad = (pr >> 1) & 1, useG = pr & 1;
     uint32_t y = i0 / t.w, x = i0 - y * t.w;
     uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
+    if (PXSZ == 3 && y > 0 && x > 0 && x + 4 < t.w) {
+        // RGB interior group (the common case): the four pixels, their left neighbour and the five above them are 15 + 15
+        // consecutive bytes: two unaligned 16-byte loads instead of 48 byte loads (the 16th byte belongs to pixel x + 4 of
+        // the same tile row, so the loads stay inside the raster)
+        typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+        const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * 3 - 3;
+        const u32x4_a1 c = *reinterpret_cast<const u32x4_a1 *>(p), u = *reinterpret_cast<const u32x4_a1 *>(p - bpr);
+        const uint32_t cp[5] = {c.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.y, c.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.z, c.y, 2) & 0xFFFFFFu,
+                                __builtin_amdgcn_alignbyte(c.w, c.z, 1) & 0xFFFFFFu, c.w & 0xFFFFFFu};
+        const uint32_t up[5] = {u.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.y, u.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.z, u.y, 2) & 0xFFFFFFu,
+                                __builtin_amdgcn_alignbyte(u.w, u.z, 1) & 0xFFFFFFu, u.w & 0xFFFFFFu};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+            m1_pixel<PXSZ>(cp[k + 1], cp[k], up[k + 1], up[k], false, false, useGrad, useG, nl, zr, zg, zb, za);
+            onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k);
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
         }
         onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
         if (++x == t.w) { x = 0; y++; }
+    }
     }
     const uint64_t o = t.pbase + i0;
     *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
