@@ -105,63 +105,6 @@ __device__ __forceinline__ void m1_pixel(uint32_t cur, uint32_t L, uint32_t U, u
 // (including the very wide / very tall tiles of images narrower than 444 px); the LDS-staged fast form
 // below takes over for ordinary tiles.
 // grid = tiles * blocks_per_tile, block = 256 (1024 pixels per block).
-template <int PXSZ>
-__global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
-                                                              const TileDesc *__restrict__ tiles, TileSel sel,
-                                                              uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
-                                                              uint8_t *__restrict__ planes, uint64_t plane_stride) {
-    const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
-    const TileDesc t = tiles[tile];
-    const uint8_t *__restrict__ raster = rasters[t.img];
-    const uint32_t i0 = (chunk * 256 + threadIdx.x) * 4;
-    if (i0 >= t.n) return;
-    const int pr = pr_from_sums(sums + (uint64_t)tile * 4, PXSZ, t.w, t.h);
-    const int useGrad = (pr >> 1) & 1, useG = pr & 1;
-    uint32_t y = i0 / t.w, x = i0 - y * t.w;
-    uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
-    if (PXSZ == 3 && y > 0 && x > 0 && x + 4 < t.w) {
-        // RGB interior group (the common case): the four pixels, their left neighbour and the five above them are 15 + 15
-        // consecutive bytes: two unaligned 16-byte loads instead of 48 byte loads (the 16th byte belongs to pixel x + 4 of
-        // the same tile row, so the loads stay inside the raster)
-        typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
-        const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * 3 - 3;
-        const u32x4_a1 c = *reinterpret_cast<const u32x4_a1 *>(p), u = *reinterpret_cast<const u32x4_a1 *>(p - bpr);
-        const uint32_t cp[5] = {c.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.y, c.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.z, c.y, 2) & 0xFFFFFFu,
-                                __builtin_amdgcn_alignbyte(c.w, c.z, 1) & 0xFFFFFFu, c.w & 0xFFFFFFu};
-        const uint32_t up[5] = {u.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.y, u.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.z, u.y, 2) & 0xFFFFFFu,
-                                __builtin_amdgcn_alignbyte(u.w, u.z, 1) & 0xFFFFFFu, u.w & 0xFFFFFFu};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
-            m1_pixel<PXSZ>(cp[k + 1], cp[k], up[k + 1], up[k], false, false, useGrad, useG, nl, zr, zg, zb, za);
-            onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k);
-        }
-    } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
-        const uint32_t i = i0 + k;
-        if (i < t.n && i > 0) {
-            const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * PXSZ;
-            const uint32_t cur = load_px<PXSZ>(p);
-            const bool row0 = y == 0, col0 = x == 0;
-            const uint32_t L = col0 ? 0u : load_px<PXSZ>(p - PXSZ);
-            const uint32_t U = row0 ? 0u : load_px<PXSZ>(p - bpr);
-            const uint32_t UL = (row0 || col0) ? 0u : load_px<PXSZ>(p - bpr - PXSZ);
-            m1_pixel<PXSZ>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
-        }
-        onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
-        if (++x == t.w) { x = 0; y++; }
-    }
-    }
-    const uint64_t o = t.pbase + i0;
-    *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
-    *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
-    *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
-    *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
-    if (PXSZ == 4) *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
-}
-
 // ---- byte-parallel (SWAR) forms of the per-pixel arithmetic for interior RGBA pixels: all four channels of a pixel
 // move through one 32-bit register (r | g<<8 | b<<16 | a<<24).
 __device__ __forceinline__ uint32_t swar_sub8(uint32_t a, uint32_t b) {  // per-byte a - b (mod 256)
@@ -203,6 +146,81 @@ __device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, 
     nl = (uint32_t)bit_width(m);
     if ((cur >> 24) == 0) { nl = NL_NONE; z &= 0xFF000000u; }  // invisible pixel: alpha symbol only (libxpng.c:502)
     return z;
+}
+
+// four interior RGB pixels (left neighbour cp[0], pixels cp[1..4]; the five above them in up[]) through the byte-parallel
+// arithmetic: the alpha byte is set to 255 on both sides, so it predicts itself and leaves a zero residual
+template <int useGrad, int useG>
+__device__ __forceinline__ void rgb_group_interior(const uint32_t *cp, const uint32_t *up, uint32_t &onl, uint32_t &orr, uint32_t &og, uint32_t &ob) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t nl;
+        const uint32_t z = m1_pixel_interior<useGrad, useG>(cp[k + 1] | 0xFF000000u, cp[k] | 0xFF000000u, up[k + 1], up[k], nl);
+        onl |= nl << (8 * k); orr |= (z & 255u) << (8 * k); og |= ((z >> 8) & 255u) << (8 * k); ob |= ((z >> 16) & 255u) << (8 * k);
+    }
+}
+
+constexpr uint32_t TG_REPS = 4;  // 1024-pixel chunks per workgroup of k_m1_transform_generic
+template <int PXSZ>
+__global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                              const TileDesc *__restrict__ tiles, TileSel sel,
+                                                              uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
+                                                              uint8_t *__restrict__ planes, uint64_t plane_stride) {
+    const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
+    const TileDesc t = tiles[tile];
+    const uint8_t *__restrict__ raster = rasters[t.img];
+    // a workgroup covers TG_REPS * 1024 consecutive pixels of its tile: the tile descriptor and the predictor flags are
+    // fetched once per thread, not once per four pixels (with one group per thread the kernel was a chain of three dependent
+    // memory round trips per short-lived wave: latency-bound at a third of either its VALU or its HBM time)
+    const int pr = pr_from_sums(sums + (uint64_t)tile * 4, PXSZ, t.w, t.h);
+    for (uint32_t rep = 0; rep < TG_REPS; rep++) {
+    const uint32_t i0 = ((chunk * TG_REPS + rep) * 256 + threadIdx.x) * 4;
+    if (i0 >= t.n) return;
+    const int useGrad = (pr >> 1) & 1, useG = pr & 1;
+    uint32_t y = i0 / t.w, x = i0 - y * t.w;
+    uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
+    if (PXSZ == 3 && y > 0 && x > 0 && x + 4 < t.w) {
+        // RGB interior group (the common case): the four pixels, their left neighbour and the five above them are 15 + 15
+        // consecutive bytes: two unaligned 16-byte loads instead of 48 byte loads (the 16th byte belongs to pixel x + 4 of
+        // the same tile row, so the loads stay inside the raster)
+        typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+        const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * 3 - 3;
+        const u32x4_a1 c = *reinterpret_cast<const u32x4_a1 *>(p), u = *reinterpret_cast<const u32x4_a1 *>(p - bpr);
+        const uint32_t cp[5] = {c.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.y, c.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.z, c.y, 2) & 0xFFFFFFu,
+                                __builtin_amdgcn_alignbyte(c.w, c.z, 1) & 0xFFFFFFu, c.w & 0xFFFFFFu};
+        const uint32_t up[5] = {u.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.y, u.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.z, u.y, 2) & 0xFFFFFFu,
+                                __builtin_amdgcn_alignbyte(u.w, u.z, 1) & 0xFFFFFFu, u.w & 0xFFFFFFu};
+        switch (pr & 3) {  // (uniform: a workgroup works on one tile)
+            case 0: rgb_group_interior<0, 0>(cp, up, onl, orr, og, ob); break;
+            case 1: rgb_group_interior<0, 1>(cp, up, onl, orr, og, ob); break;
+            case 2: rgb_group_interior<1, 0>(cp, up, onl, orr, og, ob); break;
+            default: rgb_group_interior<1, 1>(cp, up, onl, orr, og, ob); break;
+        }
+    } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+        const uint32_t i = i0 + k;
+        if (i < t.n && i > 0) {
+            const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * PXSZ;
+            const uint32_t cur = load_px<PXSZ>(p);
+            const bool row0 = y == 0, col0 = x == 0;
+            const uint32_t L = col0 ? 0u : load_px<PXSZ>(p - PXSZ);
+            const uint32_t U = row0 ? 0u : load_px<PXSZ>(p - bpr);
+            const uint32_t UL = (row0 || col0) ? 0u : load_px<PXSZ>(p - bpr - PXSZ);
+            m1_pixel<PXSZ>(cur, L, U, UL, row0, col0, useGrad, useG, nl, zr, zg, zb, za);
+        }
+        onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k); oa |= za << (8 * k);
+        if (++x == t.w) { x = 0; y++; }
+    }
+    }
+    const uint64_t o = t.pbase + i0;
+    *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
+    *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
+    *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
+    *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
+    if (PXSZ == 4) *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+    }
 }
 
 constexpr uint32_t TR_ROWS = 8, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
