@@ -493,3 +493,25 @@ def test_alpha_alphabet_sizes_on_the_wide_path(gpu, po, monkeypatch, k_syms):
         assert data == want, k_syms
         back = gpu.load(p)
     assert np.array_equal(back, np.ascontiguousarray(po.normalize_rgba(raster)))
+
+
+@pytest.mark.gpu
+def test_misaligned_tile_blobs_on_the_wide_path(gpu, po, monkeypatch, tmp_path):
+    """RGB with odd tile sizes: raw tiles (w*h*3 + 4 bytes, not a multiple of 4) in front of coded tiles, so the k words
+    and rANS blocks of the coded tiles start at every byte alignment (the wide residual kernel cuts its bit window out of
+    aligned dwords; the wide chains load words through unaligned-safe paths)."""
+    monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    from xpng_amd.synth import synth_raster
+    W, H = 1799, 1499
+    raster = synth_raster("photo", W, H, False, seed=3).copy()
+    noise = synth_raster("noise", W, H, False, seed=4)
+    raster[:, : W // 2] = noise[:, : W // 2]        # left tile columns become raw tiles, the right ones stay coded
+    raster[H // 2:, :] = np.where((np.arange(W) // 300 % 2 == 0)[None, :, None], noise[H // 2:], raster[H // 2:])
+    want = po.encode_image(1, raster)
+    p = tmp_path / "m.xpng"
+    gpu.store(1, raster, str(p))
+    assert p.read_bytes() == want
+    assert np.array_equal(gpu.load(str(p)), raster)
+    from xpng_amd.api import walk_tile_offsets
+    offs, _ = walk_tile_offsets(want[8:], 12)
+    assert any(o % 4 and want[8 + o + 3] != 0 for o in offs)   # coded tiles at odd offsets: the case is what it claims to be
