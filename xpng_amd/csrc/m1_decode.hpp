@@ -626,19 +626,25 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
                     have[c]++;
                 }
             }
-            if (live) {
+            {   // (unconditional: a branch around these loads makes the compiler copy the loaded registers into the loop-carried
+                //  ones, and a copy is a use - it waits for the loads it has just issued; lanes without a tile read their
+                //  placeholder tile's bytes, which nobody looks at)
                 const gp128 src = (gp128)(base + qoff[c]) + have[c];
 #pragma unroll
                 for (int q = 0; q < (int)SVC; q++) fl[c][q] = src[q];
             }
         }
     };
-    // (one copy of the 16-step block in the instruction stream, not SVC: the loop body stays at 8 KB, which matters when
-    // kernels of other batches share the CU's instruction cache)
+    // Two blocks per loop iteration, each followed by the service of ITS phase as a compile-time constant: every in-flight
+    // register set is then written at one fixed place of the loop body, so no register copies (= early waits) are needed
+    // and the wait in front of a landing counts only what was issued before it.
+    static_assert(SVC == 2, "the loop body below is written for two service phases");
 #pragma unroll 1
-    for (uint32_t kb = 0; kb < T; kb += 16) {
+    for (uint32_t kb = 0; kb < T; kb += 32) {
         block(kb);
-        service((int)((kb >> 4) & (SVC - 1)));
+        service(0);
+        block(kb + 16);
+        service(1);
     }
 }
 
