@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "rans2.hpp"
 
+#include <type_traits>
 namespace xpng {
 
 constexpr uint32_t WTAB_TILE_BYTES = 4096 + 9 * 256;  // alpha table (256 x 16 B) + nine context tables (16 x 16 B)
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
 //     16-byte stores.  Words past the pair's count are scratch: the next block, or k_rans2_finish, overwrites them.
 // So no s_waitcnt for a global access sits in the dependent chain (a conditional store per step does exactly that on
 // gfx9, where stores count on vmcnt).
+typedef uint32_t u32x4_enc __attribute__((ext_vector_type(4)));
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
@@ -139,13 +141,14 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
     // symbols of block b (pair symbols 16b .. 16b+15) = bytes [16b + SH, 16b + SH + 16) of `in`
     uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;  // in flight: the block after the current one
+    // (unconditional, on a clamped block index: a branch around the loads makes the compiler keep the loaded values in
+    //  temporaries and copy them into the loop-carried registers right away, and that copy waits for the load it follows)
+    const uint32_t last_blk = mysteps ? (mysteps - 1) >> 3 : 0;
     auto request = [&](uint32_t b) __attribute__((always_inline)) {
-        if (8 * b < mysteps) {
-            const uint8_t *a = in + 16ull * b;
-            const uint4 v = *reinterpret_cast<const uint4 *>(a);
-            f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
-            if (SH) f4 = *reinterpret_cast<const uint32_t *>(a + 16);
-        }
+        const uint8_t *a = in + 16ull * (b < last_blk ? b : last_blk);
+        const uint4 v = *reinterpret_cast<const uint4 *>(a);
+        f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
+        if (SH) f4 = *reinterpret_cast<const uint32_t *>(a + 16);
     };
     uint32_t sy0 = 0, sy1 = 0;  // this lane's 8 symbols of the current block, one per byte
     auto land = [&]() __attribute__((always_inline)) {
@@ -158,38 +161,47 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         sy0 = __builtin_amdgcn_perm(d1, d0, selb);
         sy1 = __builtin_amdgcn_perm(d3, d2, selb);
     };
-    // BIG: the 8 table entries of a block are fetched at its boundary, from the compact table in LDS (symbol -> rank byte ->
-    // entry) or, for a stream with more than WTC_CAP used symbols, from its full table in HBM; no table access inside a block
+    // BIG: the 8 table entries of a block are fetched ONE BLOCK AHEAD (its symbols land two blocks ahead), from the compact table
+    // in LDS (symbol -> rank byte -> entry) or, for a stream with more than WTC_CAP used symbols, from its full table in HBM
+    // (global address space: a pointer computed from a kernel argument through a struct would be generic, and flat loads also
+    // count on lgkmcnt); no table access inside a block, and every load has a whole block to return
     const bool cmp = BIG && live && p->distinct <= WTC_CAP;
     const uint8_t *lmap = ltab + (k < TPW ? k : 0) * TSTRIDE;
     const EncSym *lent = reinterpret_cast<const EncSym *>(lmap + 256);
-    const EncSym *gfull = reinterpret_cast<const EncSym *>(wtab + (uint64_t)tile * WTAB_TILE_BYTES);
-    EncSym E[8];
-    auto entries = [&]() __attribute__((always_inline)) {
-        uint32_t sy[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) sy[u] = ((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u;
-        if (cmp) {
-            uint32_t r[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) r[u] = lmap[sy[u]];
-#pragma unroll
-            for (int u = 0; u < 8; u++) E[u] = lent[r[u]];
-        } else if (live) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) E[u] = gfull[sy[u]];
-        }
-    };
-    request(0); land(); request(1);
+    typedef const __attribute__((address_space(1))) u32x4_enc *gent;
+    const gent gfull = (gent)(uintptr_t)(wtab + (uint64_t)tile * WTAB_TILE_BYTES);
     constexpr uint32_t cmpl_base = 1u << PB;
     constexpr int thr_shift = 31 - PB;
     uint64_t s = RANS_L;
     uint32_t cnt = 0;
+    // The main loop exists twice for the alpha class: with the entries from LDS (every stream of the wave has a compact table:
+    // wave-uniform) or from HBM.  One loop with both sources would merge two definitions of the in-flight registers, and the
+    // compiler implements the merge as copies right behind the loads - a wait for loads that were issued a moment ago.
+    auto run = [&](auto lds_entries) __attribute__((always_inline)) {
+    constexpr bool LDSE = decltype(lds_entries)::value;
+    EncSym E[8], En[8];
+    auto entries = [&]() __attribute__((always_inline)) {  // entries of the block whose symbols are in sy0/sy1 -> En
+        uint32_t sy[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sy[u] = ((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u;
+        if constexpr (LDSE) {
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) r[u] = lmap[sy[u]];
+#pragma unroll
+            for (int u = 0; u < 8; u++) En[u] = lent[r[u]];
+        } else {  // (lanes without a stream read their placeholder tile's table: no branch around the loads)
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; En[u] = EncSym{v.x, v.y, v.z, v.w}; }
+        }
+    };
+    request(0); land(); request(1);
     EncSym e = EncSym{0, 0, 0, 0};
     if (BIG) {
+        entries();                       // En = entries of block 0
 #pragma unroll
-        for (int u = 0; u < 8; u++) E[u] = EncSym{0, 0, 1u, 0};
-        entries();
+        for (int u = 0; u < 8; u++) E[u] = En[u];
+        land(); request(2); entries();   // symbols of block 1 land, block 2 is requested, En = entries of block 1 (in flight)
     } else e = tab[sy0 & 255u];
     for (uint32_t kb = 0; kb < T; kb += 8) {
         uint32_t cb = 0;  // words the pair has staged in this block
@@ -212,7 +224,15 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
             }
             if (!BIG) e = en;
         }
-        // ---- boundary: staged words out (lane `par` stores words 8 par .. 8 par + 7), next block's symbols land
+        // ---- boundary: the next block's symbols land FIRST (the wait in front of it then covers the load issued a block ago
+        // and nothing younger: behind this block's stores it would also wait for their acknowledgement), then the staged
+        // words go out (lane `par` stores words 8 par .. 8 par + 7) and the block after next is requested
+        if (BIG) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) E[u] = En[u];  // the next block's entries, requested a block ago
+        }
+        land();
+        asm volatile("" : "+v"(sy0), "+v"(sy1) : : "memory");  // (pins the landing in front of the stores)
         if (cb > 8 * par) {
             const uint4 *src = reinterpret_cast<const uint4 *>(wb + 8 * par);
             typedef uint32_t u32x4_a4w __attribute__((ext_vector_type(4), aligned(4)));
@@ -222,11 +242,14 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
             if (cb > 8 * par + 4) { const uint4 b2 = src[1]; dst[1] = u32x4_a4w{b2.x, b2.y, b2.z, b2.w}; }
         }
         cnt += cb;
-        land();
-        request((kb >> 3) + 2);
+        request((kb >> 3) + (BIG ? 3 : 2));
         if (BIG) entries();
         else e = tab[sy0 & 255u];
     }
+    };
+    if (!BIG) run(std::false_type{});
+    else if (__ballot(live && !cmp) == 0) run(std::true_type{});
+    else run(std::false_type{});
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
 }
 
