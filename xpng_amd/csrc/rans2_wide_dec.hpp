@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     const WDec *wd = wdec + (uint64_t)(live ? j : 0) * 10 + c;
     live = live && wd->kind == KIND;
     const uintptr_t words = live ? (uintptr_t)info[j].blob + wd->words_off : 0;
+    const uintptr_t words_safe = live ? words : (uintptr_t)dtab;  // (idle lanes still issue the block loads: any readable address)
     uint8_t *out = (c < 9 ? ctxsym : asym) + (live ? wd->out_off : 0);
     const uint32_t n = live ? wd->n : 0, pb = live ? wd->pb : 12, nw = live ? wd->nw : 0;
     const uint32_t npairs = n >> 1, mask = (1u << pb) - 1, csh = pb > (uint32_t)CBITS ? pb - CBITS : 0;
@@ -258,7 +259,6 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     uint32_t fa0 = 0, fhi = 0, fsh = 0;             // in-flight chunk: first word index, landing bound, byte misalignment
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     uint32_t qx = 0;
-    bool inflight = false;
     uint32_t wi = (rw - 1) & (WD_RING - 1);         // ring slot of w1 = words[rw - 1]; w2 = words[rw - 2] sits 4 bytes below (mirror for slot 0)
     uint32_t w1, w2;
     auto fetch_w = [&]() __attribute__((always_inline)) {
@@ -345,6 +345,10 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         T = v > T ? v : T; Tmin = v2 < Tmin ? v2 : Tmin;
     }
     T = sgpr((T + 7) & ~7u); Tmin = sgpr(Tmin);
+    // (nothing may be pending on vmcnt when the loop is entered: the compiler merges the counter state of the loop entry with
+    //  that of the back edge conservatively, and a load still in flight from before the loop turns into a wait at the top of
+    //  EVERY iteration - right behind the block loads the previous iteration has just issued)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     for (uint32_t jb = T; jb > 0;) {
         jb -= 8;
         const uint32_t wi0 = wi;
@@ -358,14 +362,13 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         rw -= (wi0 - wi) & (WD_RING - 1);  // words the pair consumed in this block (at most two per step)
         // ---- block boundary: in-flight words land, symbols out, next words requested
         // (landing first: its wait then covers only what the previous boundary issued, 8 steps ago, not this block's store)
-        if (inflight) {
+        {   // (unconditional, like the request below: fhi == 0 when nothing was requested)
             const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, PER > 4 ? q1.x : qx, q1.y, q1.z, q1.w, qx};
 #pragma unroll
             for (int i = 0; i < (int)PER; i++) {
                 const uint32_t a = fa0 + (uint32_t)i;
                 if (a < fhi) *ring_w(a) = __builtin_amdgcn_alignbyte(dw[i + 1], dw[i], fsh);
             }
-            inflight = false;
         }
         *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(WD_RING - 1);
         if (jb < npairs && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * jb) = *(const lds128 *)(uintptr_t)a_ob;
@@ -375,19 +378,21 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             const int32_t room = (int32_t)rw - (int32_t)WD_RING;
             want = want > room ? want : room;
             want = want > 0 ? want : 0;
-            if ((uint32_t)want < lo) {
-                const uint32_t a0 = (uint32_t)want + PER * par;
-                if (a0 < lo) {
-                    const uintptr_t A = words + 4ull * a0;
-                    const gptr32 p = (gptr32)(A & ~(uintptr_t)3);
-                    const u32x4_a4 v0 = *(gptr128)p;
-                    q0 = make_uint4(v0.x, v0.y, v0.z, v0.w);
-                    if (PER > 4) { const u32x4_a4 v1 = *(gptr128)(p + 4); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w); }
-                    qx = p[PER];
-                    fa0 = a0; fhi = lo; fsh = (uint32_t)(A & 3);
-                    inflight = true;
-                }
-                lof = (uint32_t)want;
+            {   // The loads are issued on every boundary, from a clamped address when there is nothing to fetch (fhi = 0 then keeps
+                // the landing from writing): a branch around them makes the compiler load into temporaries and copy those into
+                // the loop-carried registers at once - a wait for loads it has just issued, once per block.
+                const bool any = (uint32_t)want < lo;
+                const uint32_t a0r = (uint32_t)want + PER * par;
+                const bool req = any && a0r < lo;
+                const uint32_t a0 = req ? a0r : 0u;
+                const uintptr_t A = words_safe + 4ull * a0;
+                const gptr32 p = (gptr32)(A & ~(uintptr_t)3);
+                const u32x4_a4 v0 = *(gptr128)p;
+                q0 = make_uint4(v0.x, v0.y, v0.z, v0.w);
+                if (PER > 4) { const u32x4_a4 v1 = *(gptr128)(p + 4); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w); }
+                qx = p[PER];
+                fa0 = a0; fhi = req ? lo : 0u; fsh = (uint32_t)(A & 3);
+                lof = any ? (uint32_t)want : lof;
             }
         }
     }
