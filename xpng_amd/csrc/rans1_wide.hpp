@@ -119,11 +119,12 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     };
     if (live && (n & 1) && !par) put(tab[in[n - 1]]);  // libxpng.c:218-225: the odd tail goes to state0, no spill test
     uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;           // in flight: the chunk below the current one
+    // (unconditional, on a clamped chunk index; the landing below sits in front of the chunk's stores; the loop is entered with
+    //  nothing pending: see k_rans2_chain2 / DESIGN.md for what each of these avoids)
     auto request = [&](int32_t c) __attribute__((always_inline)) {
-        if (c >= 0 && (uint32_t)c < nchunks) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(in + 16ull * (uint32_t)c);
-            f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
-        }
+        const uint32_t cc = c < 0 ? 0u : ((uint32_t)c < nchunks ? (uint32_t)c : (nchunks ? nchunks - 1 : 0u));
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + 16ull * cc);
+        f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
     };
     uint32_t sy0 = 0, sy1 = 0;  // this lane's 8 symbols of the current chunk, one per byte (pair 8c + i in byte i)
     auto land = [&]() __attribute__((always_inline)) {
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
             cb += emit + other;
             if (act) put(e);
         }
-        // ---- boundary: staged words out (lane `par` stores words 8 par .. 8 par + 7), next chunk's symbols land
+        // ---- boundary: next chunk's symbols land, then the staged words go out (lane `par` stores words 8 par .. 8 par + 7)
+        land();
+        asm volatile("" : "+v"(sy0), "+v"(sy1) : : "memory");
         if (cb > 8 * par) {
             const uint4 *src = reinterpret_cast<const uint4 *>(wb + 8 * par);
             typedef uint32_t u32x4_a4w __attribute__((ext_vector_type(4), aligned(4)));
@@ -158,7 +161,6 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
             if (cb > 8 * par + 4) { const uint4 b2 = src[1]; dst[1] = u32x4_a4w{b2.x, b2.y, b2.z, b2.w}; }
         }
         cnt += cb;
-        land();
         request((int32_t)C - 2);
     }
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }

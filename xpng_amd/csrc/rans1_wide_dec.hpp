@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(T, o); T = v > T ? v : T; }
     T = sgpr((T + 7) & ~7u);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending when the loop is entered (see k_rans2_dec_chain)
     for (uint32_t tb = 0; tb < T; tb += 8) {
         const uint32_t wi0 = wi;
 #pragma unroll
