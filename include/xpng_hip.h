@@ -106,7 +106,10 @@ int xpnghip_encode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d
 uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *ctx, uint32_t img);
 
 /* Decode tiles [t0, t1).  d_blobs holds their concatenated blobs (device); tile_off[i - t0] is the byte
- * offset of tile i's blob inside d_blobs (host array from the serial size walk, libxpng.c:982). */
+ * offset of tile i's blob inside d_blobs (host array from the serial size walk, libxpng.c:982).
+ * Device buffers handed to these entry points need 64 readable bytes behind their contents (rasters, which the staged
+ * kernels read in 16-byte pieces, and blob buffers, whose last words are fetched in aligned blocks); the host-side
+ * wrappers (xpnghip_encode_tiles / xpnghip_decode_tiles / libxpng.so) allocate that themselves. */
 int xpnghip_decode_device(xpnghip_ctx *ctx, int mode, const void *d_blobs, uint64_t blobs_len,
                           const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream);
 
