@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--roofline-reps", type=int, default=50)
-    ap.add_argument("--pipeline", type=int, default=4,
+    ap.add_argument("--pipeline", type=int, default=5,
                     help="contexts (each with its own HIP stream and buffers) that consecutive steps alternate between, so the "
                          "encode of step k+1 runs beside the decode of step k; 1 = strictly serial steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")
