@@ -5,10 +5,12 @@ committed, the reference itself never enters the repo.
 
   python oracle/make_golden.py          # corpus + synthetic edge set (+ 4096^2 md5s)
   python oracle/make_golden.py --big    # additionally the 16384^2 photo RGBA md5 (slow, ~1 GiB)
+  python oracle/make_golden.py --only img_   # regenerate only the entries with that name prefix
 
 manifest.json: name -> {w,h,ch, src: "file:<name>.7" | "synth:<kind>", seven_md5,
                         L1/L2/L7: {size, md5, file?}}
-A golden .xpng is stored as a file when it is < 300 KB, otherwise only size+md5 are pinned.
+A golden .xpng is stored as a file when it is < 120 KB, otherwise only size+md5 are pinned -- except the 17 corpus images of the
+reference's test.rb, whose level-1 and level-2 files are all committed whole (BASELINE config 5).
 """
 import glob
 import hashlib
@@ -50,8 +52,15 @@ def main():
     assert po.have_ref(), "make -C oracle ref first"
     os.makedirs(GOLD, exist_ok=True)
     man = {}
+    # --only PREFIX: regenerate just the entries whose name starts with PREFIX, keep the others from the committed manifest
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    old_man = json.load(open(os.path.join(GOLD, "manifest.json"))) if only else {}
 
-    def add(name, raster, src, store_seven):
+    def add(name, raster, src, store_seven, keep_all=False):
+        if only and not name.startswith(only):
+            if name in old_man:
+                man[name] = old_man[name]
+            return
         seven = raster_to_seven(raster)
         h, w, ch = raster.shape
         ent = {"w": w, "h": h, "ch": ch, "src": src, "seven_md5": md5(seven)}
@@ -65,10 +74,13 @@ def main():
                 out, _ = po.ref_encode(level, seven, td)
                 back, _ = po.ref_decode(out, td)
                 e = {"size": len(out), "md5": md5(out), "decoded_md5": md5(back)}
-                if level != 7 and len(out) < KEEP_XPNG_BELOW:
+                if level != 7 and (keep_all or len(out) < KEEP_XPNG_BELOW):
                     fn = f"{name}.L{level}.xpng"
-                    with open(os.path.join(GOLD, fn), "wb") as f:
-                        f.write(out)
+                    if level == 2 and ent.get("L1", {}).get("md5") == e["md5"] and "file" in ent["L1"]:
+                        fn = ent["L1"]["file"]   # RGBA: level 2 falls back to level 1 (libxpng.c:755), same bytes: one file
+                    else:
+                        with open(os.path.join(GOLD, fn), "wb") as f:
+                            f.write(out)
                     e["file"] = fn
                 ent[f"L{level}"] = e
         man[name] = ent
@@ -78,9 +90,11 @@ def main():
         name = os.path.basename(p)[:-4]
         r = png_to_raster(p)
         if name in WHOLE:
-            add("img_" + name, r, f"file:img_{name}.7", True)
+            add("img_" + name, r, f"file:img_{name}.7", True, keep_all=True)
         else:  # pin the whole image by md5 only (input is not committed) ...
-            add("imgfull_" + name, r, "reference-corpus (not committed)", False)
+            # BASELINE config 5 (test.rb:28-38 image set): both golden .xpng are committed whole; the tests get the input
+            # raster back by decoding the golden with the oracle and checking seven_md5
+            add("imgfull_" + name, r, "reference-corpus (not committed)", False, keep_all=True)
         if name in CROPS:  # ... and a committed crop
             x, y, w, h = CROPS[name]
             c = np.ascontiguousarray(r[y:y + h, x:x + w])

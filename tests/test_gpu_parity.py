@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, golden_raster, small_entries
+from conftest import GOLD, corpus_entries, corpus_raster, golden_raster, small_entries
 
 pytestmark = pytest.mark.gpu
 
@@ -515,3 +515,27 @@ def test_misaligned_tile_blobs_on_the_wide_path(gpu, po, monkeypatch, tmp_path):
     from xpng_amd.api import walk_tile_offsets
     offs, _ = walk_tile_offsets(want[8:], 12)
     assert any(o % 4 and want[8 + o + 3] != 0 for o in offs)   # coded tiles at odd offsets: the case is what it claims to be
+
+
+@pytest.mark.parametrize("force_wide", [False, True])
+def test_whole_reference_corpus_both_directions(gpu, manifest, tmp_path, monkeypatch, force_wide):
+    """BASELINE config 5 / reference test.rb:28-38 on its own image set, whole images (multi-tile photographs, the three RGBA
+    images, the 1-bit flat one): xpng_load of every reference-written .xpng returns the reference's .7, and xpng_store at
+    levels 1 and 2 writes the reference's bytes.  17 images x 2 levels x 2 directions, on the narrow (one wave per chain) and
+    the forced wide (many chains per wave) entropy kernels."""
+    from xpng_amd.synth import to_seven_bytes
+    if force_wide:
+        monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    done = 0
+    for name, ent in corpus_entries(manifest):
+        raster = corpus_raster(ent)            # (oracle decode of the golden, pinned to seven_md5: checker only)
+        for level in (1, 2):
+            g = ent[f"L{level}"]
+            gold_path = os.path.join(GOLD, g["file"])
+            back = gpu.load(gold_path)                                   # decode direction: the reference's file
+            assert md5(to_seven_bytes(back)) == g["decoded_md5"], (name, level, "decode")
+            out = tmp_path / "o.xpng"
+            gpu.store(level, raster, str(out))                           # encode direction: the reference's bytes
+            assert out.read_bytes() == open(gold_path, "rb").read(), (name, level, "encode")
+            done += 1
+    assert done == 34

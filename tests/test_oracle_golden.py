@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, golden_raster, small_entries
+from conftest import GOLD, corpus_entries, corpus_raster, golden_raster, small_entries
 from oracle import pyoracle as po
 from xpng_amd.synth import to_seven_bytes
 
@@ -106,3 +106,17 @@ def test_rans2_roundtrip_edge_blocks():
         blk = po.rans2_encode(F, 256 if pb == 15 else 9, syms, pb)
         back, csz = po.rans2_decode(blk, n)
         assert csz == len(blk) and np.array_equal(back, syms), (n, hi, pb)
+
+
+def test_oracle_on_the_whole_reference_corpus(manifest):
+    """BASELINE config 5 image set (test.rb:28-38), whole images: the oracle decodes every reference-written golden to the
+    reference's .7 and re-encodes it to the reference's bytes, levels 1 and 2."""
+    for name, ent in corpus_entries(manifest):
+        raster = corpus_raster(ent)
+        assert raster.shape == (ent["h"], ent["w"], ent["ch"]), name
+        for level in (1, 2):
+            g = ent[f"L{level}"]
+            gold = open(os.path.join(GOLD, g["file"]), "rb").read()
+            assert len(gold) == g["size"] and md5(gold) == g["md5"], (name, level)
+            assert md5(to_seven_bytes(po.decode_image(gold))) == g["decoded_md5"], (name, level)
+            assert po.encode_image(level, raster) == gold, (name, level)
