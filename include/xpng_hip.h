@@ -39,6 +39,19 @@ int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w, uint64_t h
                          uint8_t **blobs, uint64_t *blobs_len);
 int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
                          int pxsz, uint8_t *raster);
+/* The same with the reference's worker count T (libxpng.c:146-151: T workers share the tile cursor, T = min(T, N)).  Here a
+ * worker is a DEVICE of this process: T >= 1 uses min(T, visible devices, N) of them, T == 0 (the reference's "auto") as many
+ * as leave each at least 256 tiles.  Every device codes one contiguous, pixel-weighted tile range from its own band of the
+ * raster; for the encode the blob ranges are gathered on the first device by peer copies (xGMI) for the concatenation of
+ * libxpng.c:764-769, then copied to the host once.  The bytes do not depend on T (tiles are coded independently).
+ * xpnghip_encode_tiles / xpnghip_decode_tiles are T = 1.  XPNG_DEVICE=<n> selects the first device (default 0); the
+ * caller's current HIP device is restored before returning. */
+int xpnghip_encode_tiles_T(uint64_t T, int mode, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz,
+                           uint8_t **blobs, uint64_t *blobs_len);
+int xpnghip_decode_tiles_T(uint64_t T, int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
+                           int pxsz, uint8_t *raster);
+/* number of devices such a call would use for a w x h image (0 = no usable device) */
+int xpnghip_devices_for(uint64_t T, uint64_t w, uint64_t h);
 
 /* ---- staged image: upload once, normalise and test on the device ------------------------------------
  *
@@ -59,6 +72,7 @@ int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uin
 int xpnghip_image_begin(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out);
 int xpnghip_image_single_colour(int *single);
 int xpnghip_image_encode(int mode, uint8_t **blobs, uint64_t *blobs_len);
+int xpnghip_image_encode_T(uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len);  /* T devices, as xpnghip_encode_tiles_T */
 int xpnghip_image_fetch(uint8_t *dst);
 void xpnghip_image_end(void);
 int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream);
@@ -106,10 +120,12 @@ int xpnghip_encode_device_batch(xpnghip_ctx *ctx, int mode, const void *const *d
 uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *ctx, uint32_t img);
 
 /* Decode tiles [t0, t1).  d_blobs holds their concatenated blobs (device); tile_off[i - t0] is the byte
- * offset of tile i's blob inside d_blobs (host array from the serial size walk, libxpng.c:982).
- * Device buffers handed to these entry points need 64 readable bytes behind their contents (rasters, which the staged
- * kernels read in 16-byte pieces, and blob buffers, whose last words are fetched in aligned blocks); the host-side
- * wrappers (xpnghip_encode_tiles / xpnghip_decode_tiles / libxpng.so) allocate that themselves. */
+ * offset of tile i's blob inside d_blobs (host array from the serial size walk, libxpng.c:982), or tile_off == NULL:
+ * the walk is done on the device (one lane per image follows the 24-bit sizes), so a caller whose blobs live in HBM never
+ * copies them back to find the offsets.
+ * Blob buffers handed to these entry points need 64 readable bytes behind their contents (their last words are fetched in
+ * aligned blocks); the host-side wrappers (xpnghip_encode_tiles / xpnghip_decode_tiles / libxpng.so) allocate that
+ * themselves.  Rasters need no slack: every kernel that reads one in 16-byte pieces clamps at w*h*pxsz bytes. */
 int xpnghip_decode_device(xpnghip_ctx *ctx, int mode, const void *d_blobs, uint64_t blobs_len,
                           const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream);
 

@@ -539,3 +539,62 @@ def test_whole_reference_corpus_both_directions(gpu, manifest, tmp_path, monkeyp
             assert out.read_bytes() == open(gold_path, "rb").read(), (name, level, "encode")
             done += 1
     assert done == 34
+
+
+def test_device_side_size_walk(gpu, po):
+    """xpnghip_decode_device[_batch] with tile_off == NULL: the serial size walk of libxpng.c:982 runs on the device (one lane per
+    image), for a caller whose blobs never leave HBM.  Same pixels as with host-walked offsets; a zeroed size word parks the
+    rest of that image's tiles and the decode reports it instead of faulting."""
+    import torch
+    from xpng_amd.synth import synth_raster
+    for (W, H, alpha, level) in [(1500, 1200, True, 1), (1501, 1203, False, 1), (1501, 1203, False, 2)]:
+        ch = 4 if alpha else 3
+        B = 3
+        rs = [synth_raster("photo", W, H, alpha, seed=s + 1) for s in range(B)]
+        ctx = gpu.Context(W, H, ch, batch=B)
+        d_r = [torch.from_numpy(r).cuda() for r in rs]
+        d_b = [torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+        lens = ctx.encode_device_batch(level, [t.data_ptr() for t in d_r], [t.data_ptr() for t in d_b])
+        d_o = [torch.zeros(W * H * ch, dtype=torch.uint8, device="cuda") for _ in range(B)]
+        ctx.decode_device_batch(level, [t.data_ptr() for t in d_b], lens, None, [t.data_ptr() for t in d_o])
+        assert ctx.decode_status() == 0
+        for i in range(B):
+            assert np.array_equal(d_o[i].cpu().numpy().reshape(H, W, ch), rs[i]), (W, H, alpha, level, i)
+        # single-image entry point, then a broken size chain in image 1
+        d_o[0].zero_()
+        ctx.decode_device(level, d_b[0].data_ptr(), lens[0], None, d_o[0].data_ptr())
+        assert ctx.decode_status() == 0 and np.array_equal(d_o[0].cpu().numpy().reshape(H, W, ch), rs[0])
+        first = int.from_bytes(d_b[1][:4].cpu().numpy().tobytes(), "little") & 0xFFFFFF
+        d_b[1][first:first + 3] = 0                                  # size field of tile 1 := 0
+        ctx.decode_device_batch(level, [t.data_ptr() for t in d_b], lens, None, [t.data_ptr() for t in d_o])
+        assert ctx.decode_status() == 1
+        ctx.close()
+
+
+@pytest.mark.parametrize("T", [2, 3])
+def test_worker_count_T_shards_tile_ranges_over_devices(gpu, po, tmp_path, monkeypatch, T):
+    """xpng_store_T / xpng_load_T with T > 1 (reference libxpng.c:146-151: T workers over the tile cursor): T devices of one
+    process each code a contiguous pixel-weighted tile range from their own band of the raster; blob ranges are gathered on
+    the first device (peer copies) for the concatenation.  On this one-GPU box the T shards are rehearsed on one device
+    (XPNG_FAKE_DEVICES); the bytes must not depend on T.  Odd widths: band starts at every 16-byte phase."""
+    from xpng_amd import api
+    from xpng_amd.synth import synth_raster
+    monkeypatch.setenv("XPNG_FAKE_DEVICES", str(T))
+    assert api.hip_lib().xpnghip_devices_for(T, 1501, 1203) == T
+    assert api.hip_lib().xpnghip_devices_for(0, 1501, 1203) == 1          # automatic: one device below 256 tiles each
+    for (W, H, alpha, level) in [(1500, 1200, True, 1), (1501, 1203, False, 1), (1501, 1203, False, 2), (1499, 1300, True, 1)]:
+        raster = synth_raster("photo", W, H, alpha, seed=7)
+        want = po.encode_image(level, raster)
+        p = tmp_path / "t.xpng"
+        gpu.store(level, raster, str(p), T=T)
+        assert p.read_bytes() == want, (W, H, alpha, level)
+        assert np.array_equal(gpu.load(str(p), T=T), raster), (W, H, alpha, level)
+        blobs = api.encode_tiles(level, raster, T=T)
+        assert blobs == want[8:]
+        assert np.array_equal(api.decode_tiles(level, blobs, W, H, raster.shape[2], T=T), raster)
+    # corrupt file on the multi-device path: rejected, not executed
+    bad = bytearray(want)
+    bad[12:16] = b"\xff\xff\xff\x7f"                                  # k size of tile 0 beyond its blob
+    p.write_bytes(bytes(bad))
+    with pytest.raises(gpu.XpngError):
+        gpu.load(str(p), T=T)

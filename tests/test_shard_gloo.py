@@ -145,3 +145,49 @@ def test_ranges_cover_all_tiles_once():
     assert max(px) / min(px) < 1.1
     y0, y1 = band_rows(tiles, *tile_ranges(1369, 8)[3])
     assert 0 < y0 < y1 <= 16384
+
+
+def _worker_steps(rank, world, port, q):
+    """bench.py's per-step exchange, exactly: table known up front, persistent scratch per pipeline slot, 3 steps whose
+    blob CONTENT changes while the lengths stay (a stale pack / receive buffer would show)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xpng_amd.shard import exchange_blobs_round_robin, image_from_round_robin
+    B = 5
+    table = [[100 + 13 * r + 7 * b for b in range(B)] for r in range(world)]     # known (world x B) length table
+    lens = table[rank]
+
+    def blob(r, b, step):  # bytes rank r holds for image b at `step`
+        return ((np.arange(table[r][b], dtype=np.int64) * (r + 3) + 11 * b + 101 * step) % 251).astype(np.uint8)
+
+    slots = [{}, {}]  # two pipeline slots, each with its own persistent scratch
+    ok = True
+    for step in range(3):
+        scratch = slots[step % 2]
+        bufs = [torch.from_numpy(np.concatenate([blob(rank, b, step), np.zeros(16, np.uint8)])) for b in range(B)]
+        recv, t2 = exchange_blobs_round_robin(bufs, lens, table=table, scratch=scratch)
+        assert t2 is table
+        for b in range(rank, B, world):
+            want = np.concatenate([blob(r, b, step) for r in range(world)])
+            ok = ok and np.array_equal(image_from_round_robin(recv, table, b, rank).numpy(), want)
+    if world > 1:
+        assert ("rr_pack" in slots[0]) and any(isinstance(k, tuple) and k[0] == "rr_recv" for k in slots[0])  # buffers were kept
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_exchange_path_over_steps_and_slots():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_steps, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True), (1, True)]

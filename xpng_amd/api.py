@@ -22,7 +22,7 @@ HIP_SYMBOLS = [
     "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
     "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range", "xpnghip_ctx_decode_status",
     "xpnghip_image_begin", "xpnghip_image_single_colour", "xpnghip_image_encode", "xpnghip_image_fetch", "xpnghip_image_end",
-    "xpnghip_normalize_device",
+    "xpnghip_normalize_device", "xpnghip_encode_tiles_T", "xpnghip_decode_tiles_T", "xpnghip_image_encode_T", "xpnghip_devices_for",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -63,6 +63,12 @@ def hip_lib():
         L.xpnghip_encode_tiles.argtypes = [C.c_int, vp, u64, u64, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
         L.xpnghip_decode_tiles.restype = C.c_int
         L.xpnghip_decode_tiles.argtypes = [C.c_int, vp, u64, u64, u64, C.c_int, vp]
+        L.xpnghip_encode_tiles_T.restype = C.c_int
+        L.xpnghip_encode_tiles_T.argtypes = [u64, C.c_int, vp, u64, u64, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
+        L.xpnghip_decode_tiles_T.restype = C.c_int
+        L.xpnghip_decode_tiles_T.argtypes = [u64, C.c_int, vp, u64, u64, u64, C.c_int, vp]
+        L.xpnghip_devices_for.restype = C.c_int
+        L.xpnghip_devices_for.argtypes = [u64, u64, u64]
         L.xpnghip_ctx_create.restype = C.c_int
         L.xpnghip_ctx_create.argtypes = [C.POINTER(vp), C.c_int, u64, u64, C.c_int]
         L.xpnghip_ctx_create_batch.restype = C.c_int
@@ -114,10 +120,12 @@ def host_lib():
             raise XpngError(f"{HOST_SO} is missing: run `make host`")
         hip_lib()
         L = C.CDLL(HOST_SO)
-        for name in ("xpng_store", "xpng_load", "store_7", "load_7"):
+        for name in ("xpng_store", "xpng_load", "store_7", "load_7", "xpng_store_T", "xpng_load_T"):
             getattr(L, name).restype = C.c_bool
         L.xpng_store.argtypes = [C.c_uint64, C.POINTER(XpngT), C.c_char_p]
         L.xpng_load.argtypes = [C.c_char_p, C.POINTER(XpngT)]
+        L.xpng_store_T.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(XpngT), C.c_char_p]
+        L.xpng_load_T.argtypes = [C.c_uint64, C.c_char_p, C.POINTER(XpngT)]
         L.store_7.argtypes = [C.POINTER(XpngT), C.c_char_p]
         L.load_7.argtypes = [C.c_char_p, C.POINTER(XpngT)]
         _host = L
@@ -136,39 +144,41 @@ _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
 
 
-def encode_tiles(mode: int, raster: np.ndarray) -> bytes:
-    """Host raster (h, w, 3|4) uint8 -> concatenated tile blobs (xpnghip_encode_tiles; H2D + kernels + D2H)."""
+def encode_tiles(mode: int, raster: np.ndarray, T: int = 1) -> bytes:
+    """Host raster (h, w, 3|4) uint8 -> concatenated tile blobs (xpnghip_encode_tiles_T; H2D + kernels + D2H) on T devices."""
     raster = np.ascontiguousarray(raster, dtype=np.uint8)
     h, w, ch = raster.shape
     p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
-    if hip_lib().xpnghip_encode_tiles(mode, raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(p), C.byref(n)):
+    if hip_lib().xpnghip_encode_tiles_T(T, mode, raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(p), C.byref(n)):
         raise XpngError("xpnghip_encode_tiles: " + _err())
     out = C.string_at(p, n.value)
     _libc.free(p)
     return out
 
 
-def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int) -> np.ndarray:
+def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int, T: int = 1) -> np.ndarray:
     raster = np.zeros((h, w, pxsz), dtype=np.uint8)
     buf = np.frombuffer(blobs, dtype=np.uint8)
-    if hip_lib().xpnghip_decode_tiles(mode, buf.ctypes.data_as(C.c_void_p), len(blobs), w, h, pxsz,
-                                      raster.ctypes.data_as(C.c_void_p)):
+    if hip_lib().xpnghip_decode_tiles_T(T, mode, buf.ctypes.data_as(C.c_void_p), len(blobs), w, h, pxsz,
+                                        raster.ctypes.data_as(C.c_void_p)):
         raise XpngError("xpnghip_decode_tiles: " + _err())
     return raster
 
 
-def store(mode: int, raster: np.ndarray, path: str) -> None:
-    """xpng_store (include/xpng.h): full host driver incl. normalisation, fallbacks and file output."""
+def store(mode: int, raster: np.ndarray, path: str, T: int = None) -> None:
+    """xpng_store[_T] (include/xpng.h): full host driver incl. normalisation, fallbacks and file output."""
     raster = np.ascontiguousarray(raster, dtype=np.uint8)
     h, w, ch = raster.shape
     pm = XpngT(raster.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, raster.size, ch == 4)
-    if host_lib().xpng_store(mode, C.byref(pm), path.encode()):
+    rc = host_lib().xpng_store(mode, C.byref(pm), path.encode()) if T is None else host_lib().xpng_store_T(T, mode, C.byref(pm), path.encode())
+    if rc:
         raise XpngError("xpng_store failed")
 
 
-def load(path: str) -> np.ndarray:
+def load(path: str, T: int = None) -> np.ndarray:
     pm = XpngT()
-    if host_lib().xpng_load(path.encode(), C.byref(pm)):
+    rc = host_lib().xpng_load(path.encode(), C.byref(pm)) if T is None else host_lib().xpng_load_T(T, path.encode(), C.byref(pm))
+    if rc:
         raise XpngError("xpng_load failed")
     out = np.ctypeslib.as_array(pm.p, shape=(pm.h, pm.w, 3 + int(pm.A))).copy()
     _libc.free(pm.p)
@@ -250,13 +260,16 @@ class Context:
         """blob_lens: bytes of each blob buffer; tile_offs: per image, the blob start offsets of tiles [t0, t1)."""
         k = len(d_blobs)
         t1 = self.n_tiles if t1 is None else t1
-        flat = [o for offs in tile_offs for o in offs]
-        assert len(flat) == k * (t1 - t0)
-        key = (tuple(flat), t0, t1)
-        if getattr(self, "_off_key", None) != key:
-            self._off_key, self._off_arr = key, (C.c_uint64 * len(flat))(*flat)
+        off_arr = None   # tile_offs None: the size walk (libxpng.c:982) runs on the device
+        if tile_offs is not None:
+            flat = [o for offs in tile_offs for o in offs]
+            assert len(flat) == k * (t1 - t0)
+            key = (tuple(flat), t0, t1)
+            if getattr(self, "_off_key", None) != key:
+                self._off_key, self._off_arr = key, (C.c_uint64 * len(flat))(*flat)
+            off_arr = self._off_arr
         ins, outs, lens = (C.c_void_p * k)(*d_blobs), (C.c_void_p * k)(*d_rasters), (C.c_uint64 * k)(*blob_lens)
-        if hip_lib().xpnghip_decode_device_batch(self._h, mode, ins, lens, k, self._off_arr, t0, t1, outs, stream):
+        if hip_lib().xpnghip_decode_device_batch(self._h, mode, ins, lens, k, off_arr, t0, t1, outs, stream):
             raise XpngError("xpnghip_decode_device_batch: " + _err())
 
     def last_blobs_len(self) -> int:
@@ -264,7 +277,7 @@ class Context:
 
     def decode_device(self, mode, d_blobs: int, blobs_len: int, tile_off, d_raster: int, t0=0, t1=None, stream=0):
         t1 = self.n_tiles if t1 is None else t1
-        arr = (C.c_uint64 * (t1 - t0))(*tile_off)
+        arr = (C.c_uint64 * (t1 - t0))(*tile_off) if tile_off is not None else None
         if hip_lib().xpnghip_decode_device(self._h, mode, d_blobs, blobs_len, arr, t0, t1, d_raster, stream):
             raise XpngError("xpnghip_decode_device: " + _err())
 

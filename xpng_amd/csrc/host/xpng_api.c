@@ -79,7 +79,7 @@ static void print_rate(const char *what, uint64_t workers, uint64_t ns, uint64_t
 /* The tile-codec path of xpng_store_T (levels 1 and 2 on a raster of more than 4 bytes): the raster is uploaded once and
  * normalize_RGBA (libxpng.c:733), the whole-image single-colour test (741-753) and the tile encode (758-769) run on the
  * device.  The normalised raster comes back to the host only for the outputs that contain it verbatim. */
-static _Bool store_on_device(uint64_t mode, const xpng_t *pm, const char *fn, uint64_t t_start) {
+static _Bool store_on_device(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn, uint64_t t_start) {
     int pxsz = 0;
     if (xpnghip_image_begin(pm->p, pm->w, pm->h, 3 + pm->A, &pxsz)) {
         fprintf(stderr, "xpng: GPU staging failed: %s\n", xpnghip_last_error());
@@ -111,11 +111,12 @@ static _Bool store_on_device(uint64_t mode, const xpng_t *pm, const char *fn, ui
     }
     {
         uint64_t blen = 0;
-        if (xpnghip_image_encode((int)mode, &blobs, &blen)) {
+        if (xpnghip_image_encode_T(T, (int)mode, &blobs, &blen)) {
             fprintf(stderr, "xpng: GPU tile encode failed: %s\n", xpnghip_last_error());
             goto done;
         }
-        print_rate("encode", 1, now_ns() - t_start, pm->w * pm->h);
+        /* the reference prints its worker-thread count here (libxpng.c:761); the workers of this library are GPUs */
+        print_rate("encode", (uint64_t)xpnghip_devices_for(T, pm->w, pm->h), now_ns() - t_start, pm->w * pm->h);
         if (blen >= s) { /* libxpng.c:771-777 */
             if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
             hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
@@ -131,7 +132,8 @@ done:
 
 _Bool xpng_store_T(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn) {
     const uint64_t t_start = now_ns();
-    (void)T; /* one GPU per process; multi-GPU sharding is driven through xpnghip_encode_device */
+    /* T: the reference's worker count (libxpng.c:146-151); here the number of GPUs of this process the tile stage may use
+     * (0 = automatic), see xpnghip_encode_tiles_T */
     if (!pm || !fn || !pm->p || !pm->w || !pm->h || pm->w > XPNG_MAX_DIM || pm->h > XPNG_MAX_DIM ||
         !(mode == 1 || mode == 2 || mode == 7) || pm->w * pm->h * (3u + pm->A) != pm->s)
         return 1; /* libxpng.c:729-731 */
@@ -144,7 +146,7 @@ _Bool xpng_store_T(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn) 
         h1[7] |= 2;
         return write_file(fn, h1, pm->p, 3);
     }
-    if (mode != 7 && pm->w * pm->h > 1) return store_on_device(mode, pm, fn, t_start);
+    if (mode != 7 && pm->w * pm->h > 1) return store_on_device(T, mode, pm, fn, t_start);
     uint8_t *owned = NULL;
     uint64_t s;
     _Bool A;
@@ -162,7 +164,6 @@ _Bool xpng_store_T(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn) 
 _Bool xpng_store(uint64_t mode, const xpng_t *pm, const char *fn) { return xpng_store_T(0, mode, pm, fn); }
 
 _Bool xpng_load_T(uint64_t T, const char *fn, xpng_t *pm) {
-    (void)T;
     if (!fn || !pm) return 1;
     FILE *f = fopen(fn, "rb");
     if (!f) return 1;
@@ -191,9 +192,9 @@ _Bool xpng_load_T(uint64_t T, const char *fn, xpng_t *pm) {
         for (uint64_t i = 0; i < pm->w * pm->h; i++) memcpy(pm->p + i * (uint64_t)pxsz, buf + 8, (size_t)pxsz);
         rc = 0;
     } else {
-        if (xpnghip_decode_tiles((int)mode, buf + 8, flen - 8, pm->w, pm->h, pxsz, pm->p))
+        if (xpnghip_decode_tiles_T(T, (int)mode, buf + 8, flen - 8, pm->w, pm->h, pxsz, pm->p))
             fprintf(stderr, "xpng: GPU tile decode failed: %s\n", xpnghip_last_error());
-        else { print_rate("decode", 1, now_ns() - t_start, pm->w * pm->h); rc = 0; }
+        else { print_rate("decode", (uint64_t)xpnghip_devices_for(T, pm->w, pm->h), now_ns() - t_start, pm->w * pm->h); rc = 0; }
     }
     free(buf);
     if (rc) { free(pm->p); pm->p = NULL; }

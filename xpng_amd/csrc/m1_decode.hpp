@@ -1057,13 +1057,33 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
 }
 
 // --------------------------------------------------------------------------------------------------
-// (re)allocate the decode workspace and bring the tile offsets to the device
+// The serial size walk of the reference decoder (libxpng.c:982: t[i].f = r.p + x; x += low24(first u32)) for a caller whose
+// blobs already live in HBM: one lane per image, cnt dependent loads.  The reference trusts the sizes; here a size that is
+// zero or leaves the buffer parks every later tile at the end of the buffer, where k_dec_parse rejects it (avail < 4).
+__global__ void k_dec_offsets(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ blob_len, uint32_t cnt,
+                              uint32_t nimg, uint64_t *__restrict__ off) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nimg) return;
+    const uint8_t *p = blobs[b];
+    const uint64_t L = blob_len[b];
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        off[(uint64_t)b * cnt + i] = o;
+        const uint32_t sz = o + 4 <= L ? ld32u(p + o) & 0xFFFFFFu : 0u;
+        o = sz ? (o + sz <= L ? o + sz : L) : L;
+    }
+}
+
+// (re)allocate the decode workspace and bring the tile offsets to the device (tile_off == nullptr: walk them there)
 inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane, const uint64_t *tile_off, uint32_t t0,
-                             uint32_t total, hipStream_t s, std::string &err) {
+                             uint32_t total, hipStream_t s, std::string &err, const uint8_t *const *d_blob_ptrs = nullptr,
+                             const uint64_t *d_blob_len = nullptr) {
     auto bad = [&](const char *m) { err = m; return 1; };
     if (ws.cap_tiles < (uint64_t)B * n_tiles || ws.cap_plane < plane) {
         decode_ws_free(ws);
-        const uint64_t sz[5] = {rup(plane + 8192, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(4 * plane + 1024, 256)};
+        // (the context symbol area carries one largest tile of slack: a corrupt payload can make the walk pop one queue for all
+        //  of a tile's steps, i.e. read up to a tile's pixel count past that queue's start)
+        const uint64_t sz[5] = {rup(plane + 8192 + 450000, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(4 * plane + 1024, 256)};
         void *pl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if (ws.arena && ws.arena_bytes >= sz[0] + sz[1] + sz[2] + sz[3] + sz[4] + 256 && !getenv("XPNG_NO_ARENA")) {
             uint8_t *q = reinterpret_cast<uint8_t *>(rup(reinterpret_cast<uintptr_t>(ws.arena), 256));
@@ -1084,6 +1104,12 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
             return bad("hipMalloc failed (decode workspace)");
         ws.d_resid = ws.d_resid_alloc + 16;
         ws.cap_tiles = (uint64_t)B * n_tiles; ws.cap_plane = plane;
+    }
+    if (!tile_off) {
+        if (!d_blob_ptrs || !d_blob_len) return bad("device-side size walk needs the blob tables");
+        k_dec_offsets<<<(B + 63) / 64, 64, 0, s>>>(d_blob_ptrs, d_blob_len, total / B, B, ws.d_off);
+        ws.last_off.clear();
+        return 0;
     }
     if (ws.last_off.size() != total || ws.last_t0 != t0 || memcmp(ws.last_off.data(), tile_off, (size_t)total * 8) != 0) {
         // pageable host memory: the copy is staged synchronously, so only pay for it when the offsets changed
@@ -1114,7 +1140,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
-    if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err)) return 1;
+    if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
     const uint64_t bpr = W * (uint64_t)pxsz;
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);

@@ -387,7 +387,7 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                             const uint64_t *d_sbase2, hipStream_t s, std::string &err) {
     const uint32_t cnt = t1 - t0, total = B * cnt;
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, nullptr};
-    if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err)) return 1;
+    if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
     const uint64_t bpr = W * 3;
     if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }
     k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2, d_status);

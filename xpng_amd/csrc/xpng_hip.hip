@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -125,8 +126,10 @@ struct xpnghip_ctx {
     int stamps = 0;  // XPNG_STAMPS=1: chain kernels record s_memtime phase stamps (debug_fetch 40/41)
     uint64_t *h_total = nullptr;  // pinned, B entries
     hipStream_t stream = nullptr;
-    // host-buffer wrappers keep their own device raster / blob buffers here
-    uint8_t *d_raster = nullptr, *d_blobs = nullptr;
+    // host-buffer wrappers keep their own device raster / blob buffers here (capacities in bytes; grown on demand, never per call)
+    uint8_t *d_raster = nullptr, *d_blobs = nullptr, *d_blob_in = nullptr;
+    uint64_t cap_raster = 0, cap_blobs = 0, cap_blob_in = 0;
+    uint64_t call = 0;  // id of the last host-wrapper call that used this context (wrappers.hpp: never evicted mid-call)
     DecodeWs dec;
 };
 
@@ -135,7 +138,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
-                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
+                    c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_blob_in, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
                     c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
@@ -147,8 +150,14 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     delete c;
 }
 
+static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch, uint64_t r0, uint64_t r1);
 extern "C" int xpnghip_ctx_create_range(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch,
                                         uint64_t r0, uint64_t r1) {
+    try { return ctx_create_range_impl(out, device, w, h, pxsz, batch, r0, r1); }
+    catch (const std::bad_alloc &) { return fail("out of host memory"); }
+    catch (...) { return fail("unexpected C++ exception"); }
+}
+static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint64_t h, int pxsz, uint32_t batch, uint64_t r0, uint64_t r1) {
     if (!out || !w || !h || w > (1u << 24) || h > (1u << 24) || (pxsz != 3 && pxsz != 4) || batch < 1 || batch > 4096 || r0 >= r1) return fail("bad arguments");
     if (xpnghip_device_count() <= device || device < 0) return fail("no such HIP device (libxpng_hip has no CPU fallback)");
     HIPCHK(hipSetDevice(device));
@@ -480,163 +489,7 @@ extern "C" int xpnghip_ctx_decode_status(xpnghip_ctx *c, void *stream) {
     return (int)(v & 1);
 }
 
-// ---- host-buffer wrappers ------------------------------------------------------------------------------
-static std::mutex g_mu;
-static xpnghip_ctx *g_cached = nullptr;
-static xpnghip_ctx *cached_ctx(uint64_t w, uint64_t h, int pxsz) {
-    if (g_cached && (g_cached->W != w || g_cached->H != h || g_cached->pxsz != pxsz)) { xpnghip_ctx_destroy(g_cached); g_cached = nullptr; }
-    if (!g_cached && xpnghip_ctx_create(&g_cached, 0, w, h, pxsz)) return nullptr;
-    return g_cached;
-}
-
-extern "C" int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz,
-                                    uint8_t **blobs, uint64_t *blobs_len) {
-    if (!raster || !blobs || !blobs_len) return fail("null argument");
-    std::lock_guard<std::mutex> lk(g_mu);
-    xpnghip_ctx *c = cached_ctx(w, h, pxsz);
-    if (!c) return 1;
-    const uint64_t s = w * h * (uint64_t)pxsz, N = c->tiles.size(), bound = xpnghip_ctx_blob_bound(c, 0, N);
-    if (!c->d_raster) HIPCHK(hipMalloc((void **)&c->d_raster, s + 64));
-    if (!c->d_blobs) HIPCHK(hipMalloc((void **)&c->d_blobs, bound + 64));
-    HIPCHK(hipMemcpyAsync(c->d_raster, raster, s, hipMemcpyHostToDevice, c->stream));
-    uint64_t len = 0;
-    if (xpnghip_encode_device(c, mode, c->d_raster, 0, N, c->d_blobs, &len, nullptr)) return 1;
-    uint8_t *out = (uint8_t *)malloc(len ? len : 1);
-    if (!out) return fail("malloc failed");
-    HIPCHK(hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost));
-    *blobs = out; *blobs_len = len;
-    return 0;
-}
-
-// ---- staged image (normalize_RGBA and the single-colour test on the device) ---------------------------
-static uint32_t *g_flags = nullptr;  // 4 device words for the OR-reductions
-static int norm_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, hipStream_t s) {
-    if (!g_flags) HIPCHK(hipMalloc((void **)&g_flags, 16));
-    HIPCHK(hipMemsetAsync(g_flags, 0, 16, s));
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((npx / 4 + 255) / 256 + 1, 256 * 16);
-    k_norm_flags<<<blocks, 256, 0, s>>>((const uint32_t *)d_rgba, npx, g_flags);
-    uint32_t f[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(f, g_flags, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    *pxsz_out = 4; *rewritten = 0;
-    if (f[0]) { k_norm_zero_hidden<<<blocks, 256, 0, s>>>((const uint32_t *)d_rgba, (uint32_t *)d_out, npx); *rewritten = 1; }
-    else if (!f[1]) { k_norm_to_rgb<<<blocks, 256, 0, s>>>((const uint32_t *)d_rgba, (uint8_t *)d_out, npx); *pxsz_out = 3; *rewritten = 1; }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-extern "C" int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream) {
-    if (!d_rgba || !d_out || !pxsz_out || !rewritten || !npx) return fail("null argument");
-    if (((uintptr_t)d_rgba & 15) || ((uintptr_t)d_out & 3)) return fail("device buffers must be 16-byte aligned");
-    std::lock_guard<std::mutex> lk(g_mu);
-    return norm_device(d_rgba, npx, d_out, pxsz_out, rewritten, (hipStream_t)stream);
-}
-
-static struct Staged {
-    bool open = false, failed = false;
-    uint64_t w = 0, h = 0, cap_in = 0, cap_norm = 0;
-    int pxsz = 0;
-    uint8_t *d_in = nullptr, *d_norm = nullptr;  // uploaded raster; rewritten raster (when normalisation changed it)
-    const uint8_t *cur = nullptr;                // the staged (normalised) raster
-} g_img;
-
-extern "C" int xpnghip_image_begin(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
-    if (!raster || !pxsz_out || !w || !h || (pxsz_in != 3 && pxsz_in != 4)) return fail("bad argument");
-    g_mu.lock();
-    auto bail = [&](const char *m) { g_mu.unlock(); return fail(m); };
-    int dev = 0;
-    if (xpnghip_device_count() < 1 || hipGetDevice(&dev) != hipSuccess) return bail("no HIP device");
-    const uint64_t s = w * h * (uint64_t)pxsz_in;
-    if (g_img.cap_in < s) {
-        if (g_img.d_in) (void)hipFree(g_img.d_in);
-        g_img.d_in = nullptr; g_img.cap_in = 0;
-        if (hipMalloc((void **)&g_img.d_in, s + 64) != hipSuccess) return bail("hipMalloc failed (staged raster)");
-        g_img.cap_in = s;
-    }
-    if (hipMemcpy(g_img.d_in, raster, s, hipMemcpyHostToDevice) != hipSuccess) return bail("raster upload failed");
-    g_img.w = w; g_img.h = h; g_img.pxsz = pxsz_in; g_img.cur = g_img.d_in; g_img.failed = false;
-    if (pxsz_in == 4) {
-        if (g_img.cap_norm < s) {
-            if (g_img.d_norm) (void)hipFree(g_img.d_norm);
-            g_img.d_norm = nullptr; g_img.cap_norm = 0;
-            if (hipMalloc((void **)&g_img.d_norm, s + 64) != hipSuccess) return bail("hipMalloc failed (normalised raster)");
-            g_img.cap_norm = s;
-        }
-        int rewritten = 0;
-        if (norm_device(g_img.d_in, w * h, g_img.d_norm, &g_img.pxsz, &rewritten, nullptr)) { g_mu.unlock(); return 1; }
-        if (rewritten) g_img.cur = g_img.d_norm;
-    }
-    *pxsz_out = g_img.pxsz;
-    g_img.open = true;
-    return 0;  // (the lock stays held until xpnghip_image_end)
-}
-extern "C" void xpnghip_image_end(void) {
-    if (!g_img.open) return;
-    g_img.open = false;
-    g_mu.unlock();
-}
-extern "C" int xpnghip_image_single_colour(int *single) {
-    if (!g_img.open || !single) return fail("no staged image");
-    const uint64_t n = g_img.w * g_img.h;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-    if (!g_flags) HIPCHK(hipMalloc((void **)&g_flags, 16));
-    HIPCHK(hipMemsetAsync(g_flags + 2, 0, 4, nullptr));
-    if (g_img.pxsz == 4) k_any_differs<4><<<blocks, 256>>>(g_img.cur, n, g_flags + 2);
-    else k_any_differs<3><<<blocks, 256>>>(g_img.cur, n, g_flags + 2);
-    uint32_t f = 0;
-    HIPCHK(hipMemcpy(&f, g_flags + 2, 4, hipMemcpyDeviceToHost));
-    *single = f ? 0 : 1;
-    return 0;
-}
-extern "C" int xpnghip_image_fetch(uint8_t *dst) {
-    if (!g_img.open || !dst) return fail("no staged image");
-    HIPCHK(hipMemcpy(dst, g_img.cur, g_img.w * g_img.h * (uint64_t)g_img.pxsz, hipMemcpyDeviceToHost));
-    return 0;
-}
-extern "C" int xpnghip_image_encode(int mode, uint8_t **blobs, uint64_t *blobs_len) {
-    if (!g_img.open || !blobs || !blobs_len) return fail("no staged image");
-    xpnghip_ctx *c = cached_ctx(g_img.w, g_img.h, g_img.pxsz);
-    if (!c) return 1;
-    const uint64_t N = c->tiles.size(), bound = xpnghip_ctx_blob_bound(c, 0, N);
-    if (!c->d_blobs) HIPCHK(hipMalloc((void **)&c->d_blobs, bound + 64));
-    HIPCHK(hipDeviceSynchronize());  // (staging ran on the null stream)
-    uint64_t len = 0;
-    if (xpnghip_encode_device(c, mode, g_img.cur, 0, N, c->d_blobs, &len, nullptr)) return 1;
-    uint8_t *out = (uint8_t *)malloc(len ? len : 1);
-    if (!out) return fail("malloc failed");
-    HIPCHK(hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost));
-    *blobs = out; *blobs_len = len;
-    return 0;
-}
-
-extern "C" int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
-                                    int pxsz, uint8_t *raster) {
-    if (!raster || !blobs) return fail("null argument");
-    std::lock_guard<std::mutex> lk(g_mu);
-    xpnghip_ctx *c = cached_ctx(w, h, pxsz);
-    if (!c) return 1;
-    const uint64_t s = w * h * (uint64_t)pxsz, N = c->tiles.size();
-    std::vector<uint64_t> off(N);
-    uint64_t o = 0;
-    for (uint64_t i = 0; i < N; i++) {  // serial size walk, libxpng.c:982
-        if (o + 4 > blobs_len) return fail("truncated file: tile table runs past the end");
-        uint32_t h0; memcpy(&h0, blobs + o, 4);
-        off[i] = o; o += h0 & 0xFFFFFF;
-    }
-    if (o > blobs_len) return fail("truncated file: last tile runs past the end");
-    if (!c->d_raster) HIPCHK(hipMalloc((void **)&c->d_raster, s + 64));
-    uint8_t *d_in = nullptr;
-    HIPCHK(hipMalloc((void **)&d_in, blobs_len + 64));
-    int rc = 1;
-    if (hipMemcpyAsync(d_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-        !xpnghip_decode_device(c, mode, d_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr)) {
-        const int st = xpnghip_ctx_decode_status(c, nullptr);
-        if (st == 1) g_err = "corrupt file: a tile header is inconsistent with the tile table";
-        else if (st == 0 && hipMemcpy(raster, c->d_raster, s, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
-    }
-    else if (g_err.empty()) g_err = "decode failed";
-    (void)hipFree(d_in);
-    return rc;
-}
+#include "wrappers.hpp"
 
 // ---- introspection for parity tests ----------------------------------------------------------------------
 extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, void *out, uint64_t cap) {
