@@ -149,7 +149,10 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
     # The rank materialises only the raster band its tiles touch.  The B rasters of a launch are DISTINCT (seeds 1..B; image 0
     # is the one the manifest pins): identical rasters would sit in the 256 MB Infinity Cache for the roofline kernels and
     # would make every lane of the wide entropy kernels take the same branches.
-    bands = [synth_raster_torch(kind, W, y1 - y0, alpha, seed=1 + b, y0=y0, device=env.dev) for b in range(B)]
+    # (+ one spare row when the band is not the tail of the image: the staged 16-byte loads of the band's last row may run a few
+    # bytes past it - the kernels clamp at the end of the whole raster, which a band in the middle does not reach)
+    band_stores = [synth_raster_torch(kind, W, min(H, y1 + 1) - y0, alpha, seed=1 + b, y0=y0, device=env.dev) for b in range(B)]
+    bands = [bs[: y1 - y0] for bs in band_stores]
     band = bands[0]
     bpr = W * ch
     stream = torch.cuda.current_stream().cuda_stream
@@ -288,7 +291,7 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
     res["host_raster"] = band.cpu().numpy() if (world == 1 and rank == 0) else None
     for sl in slots:
         sl["ctx"].close()
-    del slots, bands, d_blobs_all, d_back_all, ref_blobs
+    del slots, bands, band_stores, d_blobs_all, d_back_all, ref_blobs
     torch.cuda.empty_cache()
     return res
 

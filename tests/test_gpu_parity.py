@@ -83,7 +83,8 @@ def test_load_decodes_reference_goldens(gpu, manifest, po, tmp_path):
 
 
 @pytest.mark.parametrize("kind,w,h,alpha", [("photo", 700, 500, True), ("photo", 1500, 1200, False), ("noise", 700, 500, True),
-                                            ("photo", 100, 2000, True), ("photo", 2000, 100, False), ("flat", 889, 445, True)])
+                                            ("photo", 100, 2000, True), ("photo", 2000, 100, False), ("flat", 889, 445, True),
+                                            ("photo", 1333, 901, False), ("noise", 1501, 1203, False), ("photo", 447, 446, False)])
 def test_stage_planes_and_streams_match_oracle(gpu, po, kind, w, h, alpha):
     """BASELINE config 2 parity: chooser + per-pixel transform planes, then streams and rANS blocks, per tile."""
     import torch

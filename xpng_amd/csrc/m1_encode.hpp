@@ -38,6 +38,13 @@ __global__ __launch_bounds__(256) void k_chooser(const uint8_t *const *__restric
         if (pair_loads) {
             const uint2 a = *reinterpret_cast<const uint2 *>(p - 4), b = *reinterpret_cast<const uint2 *>(p - bpr - 4);
             L = a.x; cur = a.y; UL = b.x; U = b.y;
+        } else if (PXSZ == 3) {
+            // left + current pixel = 6 consecutive bytes: one unaligned 8-byte load that ENDS with the current pixel (so it
+            // never leaves the raster; x >= 3, so it does not start in front of it either) instead of six byte loads
+            typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+            const u32x2_a1 a = *reinterpret_cast<const u32x2_a1 *>(p - 5), b = *reinterpret_cast<const u32x2_a1 *>(p - bpr - 5);
+            L = __builtin_amdgcn_alignbyte(a.y, a.x, 2) & 0xFFFFFFu; cur = a.y >> 8;
+            UL = __builtin_amdgcn_alignbyte(b.y, b.x, 2) & 0xFFFFFFu; U = b.y >> 8;
         } else {
             cur = load_px<PXSZ>(p); L = load_px<PXSZ>(p - PXSZ); U = load_px<PXSZ>(p - bpr); UL = load_px<PXSZ>(p - bpr - PXSZ);
         }
@@ -395,6 +402,142 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
         case 1: transform_phase2<0, 1>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
         case 2: transform_phase2<1, 0>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
         default: transform_phase2<1, 1>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K2 (fast form, RGB)  the same LDS-staged transform for 3-byte pixels (14 of the reference's 17 corpus images, and the only
+// input of level 2).  Phase 1 is the RGBA kernel's: rows y0-1 .. y0+R-1 of the tile leave HBM as coalesced, 16-byte aligned
+// loads and keep their global 16-byte phase in LDS.  Phase 2: a thread owns 4 consecutive pixels of the tile; the 15 bytes
+// "left neighbour + 4 pixels" of its row and of the row above are two 16-byte LDS reads at byte granularity (lane stride 12
+// bytes: conflict-free), the pixels are cut out with v_alignbyte and go through the byte-parallel arithmetic with the alpha
+// byte forced to 255 on both sides (it predicts itself: zero residual).  Four planes, one aligned dword store each.
+constexpr uint32_t TR3_LDS_PAD = 16;  // the read of a column-0 group starts 3 bytes in front of its row
+template <int useGrad, int useG>
+__device__ __forceinline__ void transform_phase2_rgb(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint64_t g0, uint32_t y0, uint32_t first,
+                                                     uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride) {
+    typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
+    uint32_t yy = (threadIdx.x * 4) / t.w, x0 = threadIdx.x * 4 - yy * t.w;
+    const uint32_t dy = 1024 / t.w, dx = 1024 - dy * t.w;
+    const uint32_t ph0 = (uint32_t)(g0 & 15), bl = (uint32_t)(bpr & 15);
+    auto row_off = [&](uint32_t lr) { return TR3_LDS_PAD + lr * TR_PITCH + ((ph0 + lr * bl) & 15u); };  // LDS byte offset of column 0 of staged row lr
+    auto px_at = [&](uint32_t lr, uint32_t x) {  // one pixel out of LDS (two aligned dwords)
+        const uint32_t a = row_off(lr) + 3 * x;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(rows + (a & ~3u));
+        return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u) & 0xFFFFFFu;
+    };
+    for (uint32_t g = threadIdx.x; g < groups; g += 256, yy += dy, x0 += dx) {
+        if (x0 >= t.w) { x0 -= t.w; yy++; }
+        const uint32_t j0 = g * 4;
+        uint32_t x = x0;
+        uint32_t onl = 0, orr = 0, og = 0, ob = 0;
+        const uint32_t lr = yy + (y0 - first);
+        const bool row0 = (y0 + yy) == 0;
+        if (j0 + 3 < strip_px && !row0) {
+            uint32_t z[4], n4[4];
+            if (x + 3 < t.w) {  // the four pixels share a row: 15 + 15 bytes
+                const uint32_t a = row_off(lr) + 3 * x - 3;
+                const u32x4_a1 c = *reinterpret_cast<const u32x4_a1 *>(rows + a), u = *reinterpret_cast<const u32x4_a1 *>(rows + a - TR_PITCH - ((ph0 + lr * bl) & 15u) + ((ph0 + (lr - 1) * bl) & 15u));
+                const uint32_t cp[5] = {c.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.y, c.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(c.z, c.y, 2) & 0xFFFFFFu,
+                                        __builtin_amdgcn_alignbyte(c.w, c.z, 1) & 0xFFFFFFu, c.w & 0xFFFFFFu};
+                const uint32_t up[5] = {u.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.y, u.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.z, u.y, 2) & 0xFFFFFFu,
+                                        __builtin_amdgcn_alignbyte(u.w, u.z, 1) & 0xFFFFFFu, u.w & 0xFFFFFFu};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    z[k] = m1_pixel_interior<useGrad, useG>(cp[k + 1] | 0xFF000000u, cp[k] | 0xFF000000u, up[k + 1] | 0xFF000000u, up[k] | 0xFF000000u, n4[k], k == 0 && x == 0);
+            } else {            // a group that straddles two rows (tile width not a multiple of 4): pixel by pixel
+                uint32_t xx = x, ll = lr;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t cur = px_at(ll, xx), L = xx ? px_at(ll, xx - 1) : 0u, U = px_at(ll - 1, xx), UL = xx ? px_at(ll - 1, xx - 1) : 0u;
+                    z[k] = m1_pixel_interior<useGrad, useG>(cur | 0xFF000000u, L | 0xFF000000u, U | 0xFF000000u, UL | 0xFF000000u, n4[k], xx == 0);
+                    if (++xx == t.w) { xx = 0; ll++; }
+                }
+            }
+            onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
+            const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u), t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);
+            const uint32_t t23lo = __builtin_amdgcn_perm(z[3], z[2], 0x05010400u), t23hi = __builtin_amdgcn_perm(z[3], z[2], 0x07030602u);
+            orr = __builtin_amdgcn_perm(t23lo, t01lo, 0x05040100u);
+            og = __builtin_amdgcn_perm(t23lo, t01lo, 0x07060302u);
+            ob = __builtin_amdgcn_perm(t23hi, t01hi, 0x05040100u);
+        } else {  // the tile's first row and the last, partial group of a strip: pixel by pixel, every case
+            uint32_t y = yy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t nl = NL_NONE, zr = 0, zg = 0, zb = 0, za = 0;
+                if (j0 + k < strip_px && (y0 + y + x) != 0) {
+                    const uint32_t l2 = y + (y0 - first);
+                    const bool r0 = (y0 + y) == 0, c0 = x == 0;
+                    const uint32_t cur = px_at(l2, x), L = c0 ? 0u : px_at(l2, x - 1), U = r0 ? 0u : px_at(l2 - 1, x), UL = (r0 || c0) ? 0u : px_at(l2 - 1, x - 1);
+                    m1_pixel<3>(cur, L, U, UL, r0, c0, useGrad, useG, nl, zr, zg, zb, za);
+                }
+                onl |= nl << (8 * k); orr |= zr << (8 * k); og |= zg << (8 * k); ob |= zb << (8 * k);
+                if (++x == t.w) { x = 0; y++; }
+            }
+        }
+        const uint64_t o = t.pbase + (uint64_t)y0 * t.w + j0;
+        *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
+        *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
+        *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
+        *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+                                                          uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                          uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
+                                                          uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks) {
+    __shared__ __align__(16) uint8_t rows[TR3_LDS_PAD + (TR_ROWS + 1) * TR_PITCH + 16];
+    const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware: consecutive strips of a tile on one XCD
+    if (bid >= nblocks) return;
+    const uint32_t tile = vtile(sel, bid / strips_per_tile), strip = bid % strips_per_tile;
+    const TileDesc t = tiles[tile];
+    const uint32_t y0 = strip * TR_ROWS;
+    if (y0 >= t.h) return;
+    const uint8_t *__restrict__ raster = rasters[t.img];
+    const uint32_t nrows = min(TR_ROWS, t.h - y0);
+    const uint32_t first = y0 ? y0 - 1 : 0, lrows = y0 + nrows - first;
+    const uint64_t g0 = (uint64_t)(t.y + first) * bpr + (uint64_t)t.x * 3;  // first staged byte
+    {   // ---- phase 1: global -> LDS, 16 bytes per lane per load, every load in flight before the first LDS store
+        const uint32_t row_bytes = t.w * 3;
+        const uint32_t chunks = ((15u + row_bytes + 15u) >> 4) + 1;  // per row, upper bound for any phase
+        constexpr int LD = ((TR_ROWS + 1) * (TR_MAXW * 3 / 16 + 3) + 255) / 256;
+        const uint32_t total_chunks = lrows * chunks;
+        const float inv_chunks = 1.0f / (float)chunks;
+        uint4 v[LD];
+        uint32_t dst[LD];
+#pragma unroll
+        for (int k = 0; k < LD; k++) {
+            const uint32_t idx = threadIdx.x + 256u * k;
+            dst[k] = ~0u;
+            if (idx < total_chunks) {
+                uint32_t r = (uint32_t)((float)idx * inv_chunks);
+                if (r * chunks > idx) r--;
+                if ((r + 1) * chunks <= idx) r++;
+                const uint32_t ch = idx - r * chunks;
+                const uint64_t gr = g0 + (uint64_t)r * bpr;
+                const uint64_t a = (gr & ~15ull) + (uint64_t)ch * 16;
+                if (a < gr + row_bytes) {
+                    dst[k] = TR3_LDS_PAD + r * TR_PITCH + ch * 16;
+                    if (a + 16 <= raster_bytes) v[k] = *reinterpret_cast<const uint4 *>(raster + a);
+                    else {  // last chunk of the raster: stay inside the allocation (a raster need not be a multiple of 4 bytes long)
+                        uint32_t w4[4] = {0, 0, 0, 0};
+                        for (uint32_t q = 0; q < 16; q++) if (a + q < raster_bytes) w4[q >> 2] |= (uint32_t)raster[a + q] << (8 * (q & 3));
+                        v[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
+    }
+    __syncthreads();
+    switch (pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3) {
+        case 0: transform_phase2_rgb<0, 0>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
+        case 1: transform_phase2_rgb<0, 1>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
+        case 2: transform_phase2_rgb<1, 0>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
+        default: transform_phase2_rgb<1, 1>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
     }
 }
 

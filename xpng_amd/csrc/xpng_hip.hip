@@ -299,6 +299,9 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     if (PXSZ == 4 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
         k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
+    } else if (PXSZ == 3 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
+        const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
+        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
     } else {
         const uint32_t bpt = (max_n + 1024 * TG_REPS - 1) / (1024 * TG_REPS);
         k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride);
