@@ -198,62 +198,116 @@ __device__ inline uint32_t rans2_encode_block(const uint8_t *__restrict__ in, ui
     uint64_t s = RANS_L;
     uint32_t cnt = 0, flushed = 0;  // wave-uniform
     {
-        // symbol supply: the stream is staged through a 2 KB LDS ring in 1 KB units, copied coalesced by the whole
-        // wave; the unit after the newest one sits prefetched in registers (one 16-byte load per lane in flight).
-        __shared__ __align__(16) uint8_t sring[2048];
+        // Symbol supply: the stream is staged through a 2 KB LDS ring in 1 KB units, copied coalesced by the whole wave (the ring
+        // keeps the stream's 16-byte phase in memory; its first 16 bytes are mirrored behind its end, so that an 8-byte window
+        // read at any byte position never wraps); the unit after the newest one sits prefetched in registers.
+        // The recurrence itself runs in straight-line double blocks of 8 steps in which NOTHING waits on a load just issued:
+        //   * a block's 8 symbols (4 per state) are one unaligned 8-byte LDS read issued two blocks ahead;
+        //   * its four table entries (16 B each) are read one block ahead, with addresses cut out of that window;
+        //   * the renormalisation (spill test -> ring store -> shift) sits behind a wave-uniform branch that skewed streams
+        //     take once in tens of steps, so the common step is: decode entry, compare, 64x64 high multiply, shift, mad;
+        //   * ring flush and unit refill are checked once per 128 steps, outside the straight-line loop.
+        __shared__ __align__(16) uint8_t sring[2048 + 16];
         const uint8_t *inA = reinterpret_cast<const uint8_t *>((uintptr_t)in & ~(uintptr_t)15);
         const uint32_t p0 = (uint32_t)((uintptr_t)in & 15);  // ring position of symbol 0
         const uint4 *src = reinterpret_cast<const uint4 *>(inA) + lane;
-        reinterpret_cast<uint4 *>(sring)[lane] = src[0];
-        reinterpret_cast<uint4 *>(sring)[64 + lane] = src[64];
+        {
+            const uint4 u0 = src[0];
+            reinterpret_cast<uint4 *>(sring)[lane] = u0;
+            if (lane == 0) reinterpret_cast<uint4 *>(sring)[128] = u0;  // mirror
+            reinterpret_cast<uint4 *>(sring)[64 + lane] = src[64];
+        }
         uint4 pre = src[128];
         uint32_t filled = 2;        // units already in the ring (uniform)
-        uint32_t pos = sgpr(p0);    // ring position of the next symbol PAIR to hand out (uniform)
         __syncthreads();
-        auto next_sym = [&]() -> uint32_t {
-            if (pos + 8 >= filled * 1024u) {  // uniform: rotate the prefetched unit in, start the next load
-                __syncthreads();
-                reinterpret_cast<uint4 *>(sring)[(filled & 1u) * 64 + lane] = pre;
-                filled++;
-                pre = src[filled * 64];
-                __syncthreads();
-            }
-            const uint32_t sy = sring[(pos + par) & 2047u];
-            pos += 2;
-            return sy;
+        typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+        auto window = [&](uint32_t pos) -> u32x2_a1 { return *reinterpret_cast<const u32x2_a1 *>(sring + (pos & 2047u)); };
+        // entry of the symbol in byte (2u + par) of a window
+        const uint32_t bsh = 8u * par;
+        auto entry = [&](const u32x2_a1 &W, int u) -> EncSym {
+            const uint32_t d = u < 2 ? W.x : W.y;
+            const uint32_t sy = (d >> (bsh + 16u * (uint32_t)(u & 1))) & 255u;
+            return tab[sy];
         };
-        auto step = [&](const EncSym &e) {
+        auto step = [&](const EncSym &e) __attribute__((always_inline)) {
             const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
             const bool emit = (uint32_t)(s >> 32) >= (freq << thr_shift);
             const uint32_t m = sgpr((uint32_t)__ballot(emit) & 3u);  // bit0: state0 spills, bit1: state1 spills
-            const uint32_t e0 = m & 1u;
-            if (emit) {
-                if (lane < 2) ring[(cnt + (par ? e0 : 0u)) & 511u] = (uint32_t)s;
-                s >>= 32;
+            if (m) {  // uniform, rare for skewed streams
+                const uint32_t e0 = m & 1u;
+                if (emit) {
+                    if (lane < 2) ring[(cnt + (par ? e0 : 0u)) & 511u] = (uint32_t)s;  // state0's word first (libxpng.c:370-373)
+                    s >>= 32;
+                }
+                cnt += e0 + (m >> 1);
             }
-            cnt += e0 + (m >> 1);
             const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
             const uint64_t q = __umul64hi(s, rcp) >> rsh;
             s += e.bias + q * (uint64_t)(cmpl_base - freq);
-            if (cnt - flushed >= 256) {  // uniform
-                __syncthreads();
-                for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
-                flushed += 256;
-                __syncthreads();
-            }
         };
         const uint32_t pairs = sgpr(n >> 1);  // steps in which both states code a symbol
-        EncSym ea = tab[next_sym()], eb = tab[next_sym()], ec = tab[next_sym()];
-        uint32_t k = 0;
-        for (; k + 3 <= pairs; k += 3) {
-            step(ea); ea = tab[next_sym()];
-            step(eb); eb = tab[next_sym()];
-            step(ec); ec = tab[next_sym()];
+        const uint32_t n8 = pairs >> 3;        // straight-line double blocks
+        uint32_t pos = sgpr(p0);               // ring position of the next block's first symbol (uniform)
+        uint32_t db = 0;
+        if (n8) {
+            u32x2_a1 Wa = window(pos), Wb = window(pos + 8);
+            EncSym Ea[4], Eb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) Ea[u] = entry(Wa, u);
+            while (db < n8) {
+                // ---- maintenance, once per 16 double blocks (128 steps: at most 256 words, exactly 256 symbol bytes)
+                if (cnt - flushed >= 256) {
+                    __syncthreads();
+                    for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
+                    flushed += 256;
+                    __syncthreads();
+                }
+                if (filled * 1024u < pos + 256u + 48u) {  // the windows of this round reach into the next unit: rotate it in
+                    __syncthreads();
+                    reinterpret_cast<uint4 *>(sring)[(filled & 1u) * 64 + lane] = pre;
+                    if ((filled & 1u) == 0 && lane == 0) reinterpret_cast<uint4 *>(sring)[128] = pre;
+                    filled++;
+                    pre = src[filled * 64];
+                    __syncthreads();
+                }
+                const uint32_t stop = sgpr(db + 16 < n8 ? db + 16 : n8);
+#pragma unroll 1
+                for (; db < stop; db++) {
+                    // block A: its entries Ea are here; window of block B is here (Wb); request the window after, B's entries
+                    Wa = window(pos + 16);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) Eb[u] = entry(Wb, u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) step(Ea[u]);
+                    // block B
+                    Wb = window(pos + 24);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) Ea[u] = entry(Wa, u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) step(Eb[u]);
+                    pos += 16;
+                }
+            }
         }
-        if (k < pairs) { step(ea); ea = eb; eb = ec; k++; }
-        if (k < pairs) { step(ea); ea = eb; k++; }
+        // ---- tail: fewer than 8 pair steps and the odd symbol, one at a time straight from the ring
+        __syncthreads();
+        if (cnt - flushed >= 256) {  // (the last round may have left up to 511 words staged: make room for the tail's)
+            for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
+            flushed += 256;
+            __syncthreads();
+        }
+        if (filled * 1024u < pos + 64u) {
+            reinterpret_cast<uint4 *>(sring)[(filled & 1u) * 64 + lane] = pre;
+            if ((filled & 1u) == 0 && lane == 0) reinterpret_cast<uint4 *>(sring)[128] = pre;
+            filled++;
+            __syncthreads();
+        }
+        for (uint32_t k = n8 * 8; k < pairs; k++) {
+            step(tab[sring[(pos + par) & 2047u]]);
+            pos += 2;
+        }
         if (n & 1) {  // odd tail: state0 only (libxpng.c:382-392); odd lanes skip the update
-            const EncSym e = ea;
+            const EncSym e = tab[sring[pos & 2047u]];
             const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
             const bool emit = par == 0 && (uint32_t)(s >> 32) >= (freq << thr_shift);
             const uint32_t e0 = sgpr((uint32_t)__ballot(emit) & 1u);
