@@ -185,12 +185,13 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
                                                      uint32_t c_count, int only_over, uint8_t *__restrict__ ctxsym,
                                                      uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg,
                                                      const WDec *__restrict__ wdec = nullptr) {
-    __shared__ uint8_t coarse[1 << (MAXPB - 3)];  // symbol owning slot (i << 3): start of a short forward scan (8x less LDS than a
-                                                    // full slot table, which is what bounds the number of resident chains per CU)
+    // per group of 8 slots: (F | cum << 16, symbol) of the symbol owning slot (g << 3): ONE LDS read resolves a slot whose group
+    // lies inside one symbol's range (wide symbols: the probable ones), else a short forward scan over fc[] follows
+    __shared__ uint2 coarse[1 << (MAXPB - 3)];
     __shared__ uint32_t fc[256];
     __shared__ uint32_t Fs[260];
     __shared__ uint32_t wring[512];
-    __shared__ uint8_t oring[512];
+    __shared__ __align__(8) uint8_t oring[512];
     const uint32_t j = blockIdx.x / c_count, c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63, par = lane & 1;
     if (only_over == 2 && wdec[(uint64_t)j * 10 + c].kind != 2) return;  // wide mode: only what k_rans2_dec_prep left to this kernel
     const DecTile d = info[j];
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
                 if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
             }
             while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
-            coarse[g] = (uint8_t)lo;
+            coarse[g] = make_uint2(fc[lo], lo);
         }
     }
     __syncthreads();
@@ -289,44 +290,78 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
     for (uint32_t i = ring_lo + lane; i < nw; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
     uint64_t s = ld64u(sp + 8 * par);
     __syncthreads();
-    auto refill = [&]() {  // uniform: bring the next lower 256 words into the ring before the cursor reaches them
-        if (ring_lo > 0 && rw < ring_lo + 128) {
-            const uint32_t new_lo = ring_lo > 256 ? ring_lo - 256 : 0;
-            __syncthreads();
-            for (uint32_t i = new_lo + lane; i < ring_lo; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
-            ring_lo = new_lo;
-            __syncthreads();
-        }
-    };
-    auto flush = [&](uint32_t base) {  // uniform: symbols [base, min(base+512, n)) leave the LDS ring
-        __syncthreads();
-        const uint32_t hi = base + 512 < n ? base + 512 : n;
-        for (uint32_t i = base + lane; i < hi; i += 64) out[i] = oring[i & 511u];
-        __syncthreads();
-    };
-    auto decode_one = [&](uint32_t &sym) {  // one symbol out of this lane's state; returns whether it must refill
-        const uint32_t slot = (uint32_t)s & mask;
-        const uint32_t d0 = slot - C0, d1 = slot - C1;
-        const bool hit0 = d0 < F0, hit1 = d1 < F1;
-        uint32_t F, off;
-        if (__ballot(!(hit0 || hit1)) == 0) {
-            F = hit0 ? F0 : F1; off = hit0 ? d0 : d1; sym = hit0 ? sym0 : sym1;
-        } else {
-            sym = coarse[slot >> 3];
-            uint32_t e = fc[sym];
-            while (slot - (e >> 16) >= (e & 0xFFFF) && sym + 1 < N) e = fc[++sym];  // walk to the symbol whose [cum, cum+F) holds the slot
-            F = e & 0xFFFF; off = slot - (e >> 16);
-        }
-        s = (uint64_t)F * (s >> pb) + off;
-        return s < RANS_L;
-    };
+    // The step pieces below are MACROS, not lambdas: with by-reference closures used from three loops (prologue, straight-line
+    // blocks, epilogue) the compiler kept the closures - and with them the state, the cursors and the word candidates - in
+    // scratch memory behind pointers (ScratchSize 464, a scratch access every few instructions of the chain).
+    // uniform: bring the next lower 256 words into the ring before the cursor reaches them
+#define XPNG_DEC_REFILL()                                                                                         \
+    do {                                                                                                          \
+        if (ring_lo > 0 && rw < ring_lo + 128) {                                                                  \
+            const uint32_t new_lo_ = ring_lo > 256 ? ring_lo - 256 : 0;                                           \
+            __syncthreads();                                                                                      \
+            for (uint32_t i_ = new_lo_ + lane; i_ < ring_lo; i_ += 64) wring[i_ & 511u] = ld32u(words + 4ull * i_); \
+            ring_lo = new_lo_;                                                                                    \
+            __syncthreads();                                                                                      \
+        }                                                                                                         \
+    } while (0)
+    // uniform: symbols [base, min(base+512, n)) leave the LDS ring
+#define XPNG_DEC_FLUSH(base)                                                                                      \
+    do {                                                                                                          \
+        __syncthreads();                                                                                          \
+        const uint32_t hi_ = (base) + 512 < n ? (base) + 512 : n;                                                 \
+        for (uint32_t i_ = (base) + lane; i_ < hi_; i_ += 64) out[i_] = oring[i_ & 511u];                          \
+        __syncthreads();                                                                                          \
+    } while (0)
+    // one symbol out of this lane's state -> sym; need = the state must refill
+#define XPNG_DEC_ONE(sym, need)                                                                                   \
+    do {                                                                                                          \
+        const uint32_t slot_ = (uint32_t)s & mask;                                                                \
+        const uint32_t d0_ = slot_ - C0, d1_ = slot_ - C1;                                                        \
+        const bool hit0_ = d0_ < F0, hit1_ = d1_ < F1;                                                            \
+        uint32_t F_, off_;                                                                                        \
+        if (__ballot(!(hit0_ || hit1_)) == 0) {                                                                   \
+            F_ = hit0_ ? F0 : F1; off_ = hit0_ ? d0_ : d1_; sym = hit0_ ? sym0 : sym1;                            \
+        } else {                                                                                                  \
+            const uint2 cg_ = coarse[slot_ >> 3];                                                                 \
+            sym = cg_.y;                                                                                          \
+            uint32_t e_ = cg_.x;                                                                                  \
+            while (slot_ - (e_ >> 16) >= (e_ & 0xFFFF) && sym + 1 < N) e_ = fc[++sym];  /* to the symbol whose [cum, cum+F) holds the slot */ \
+            F_ = e_ & 0xFFFF; off_ = slot_ - (e_ >> 16);                                                          \
+        }                                                                                                         \
+        s = (uint64_t)F_ * (s >> pb) + off_;                                                                      \
+        need = s < RANS_L;                                                                                        \
+    } while (0)
+    // uniform, rare: state1 refills first (libxpng.c:486-487); the candidates words[rw-1], words[rw-2] live in registers and are
+    // re-read from the LDS ring only in the steps that consumed one
+#define XPNG_DEC_RENORM(need, m)                                                          \
+    do {                                                                                  \
+        const uint32_t n1_ = (m) >> 1, n0_ = (m) & 1u;                                    \
+        const uint32_t wsel_ = par ? w1 : (n1_ ? w2 : w1);                                \
+        if (need) s = (s << 32) | wsel_;                                                  \
+        rw = rw > n0_ + n1_ ? rw - (n0_ + n1_) : 0;                                       \
+        XPNG_DEC_REFILL();                                                                \
+        w1 = wring[(rw > 0 ? rw - 1 : 0) & 511u];                                         \
+        w2 = wring[(rw > 1 ? rw - 2 : 0) & 511u];                                         \
+    } while (0)
+#define XPNG_DEC_PAIR()                                                                   \
+    do {                                                                                  \
+        i -= 2;                                                                           \
+        uint32_t sym_ = 0;                                                                \
+        bool need_;                                                                       \
+        XPNG_DEC_ONE(sym_, need_);                                                        \
+        const uint32_t m_ = sgpr((uint32_t)__ballot(need_) & 3u);                         \
+        if (lane < 2) oring[(i + par) & 511u] = (uint8_t)sym_;                            \
+        if (m_) XPNG_DEC_RENORM(need_, m_);                                               \
+        if ((i & 511u) == 0) XPNG_DEC_FLUSH(i);                                           \
+    } while (0)
     rw = sgpr(rw); ring_lo = sgpr(ring_lo);
     uint32_t i = sgpr(n);  // scalar
     if (n & 1) {  // odd tail comes from state0 only (libxpng.c:471-476)
         i--;
         uint32_t sym = 0;
         const uint64_t keep = s;
-        const bool need = decode_one(sym);
+        bool need;
+        XPNG_DEC_ONE(sym, need);
         if (par) s = keep;
         const uint32_t need0 = sgpr((uint32_t)__ballot(need && !par) & 1u);
         if (need0) {
@@ -334,28 +369,37 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
             if (!par) s = (s << 32) | wring[rw & 511u];
         }
         if (lane == 0) oring[i & 511u] = (uint8_t)sym;
-        if ((i & 511u) == 0) flush(i);
+        if ((i & 511u) == 0) XPNG_DEC_FLUSH(i);
     }
-    // The two candidate words words[rw-1], words[rw-2] live in registers and are re-read from the LDS ring only in the
-    // (wave-uniform) steps that actually consumed one: skewed streams renormalise once per tens of steps, so most steps
-    // issue no LDS word read at all.  Decoded symbols are packed 4 steps deep per lane before they touch the LDS ring.
     uint32_t w1 = wring[(rw > 0 ? rw - 1 : 0) & 511u], w2 = wring[(rw > 1 ? rw - 2 : 0) & 511u];
-    while (i >= 2) {
-        i -= 2;
-        uint32_t sym = 0;
-        const bool need = decode_one(sym);
-        const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
-        if (lane < 2) oring[(i + par) & 511u] = (uint8_t)sym;
-        if (m) {  // uniform, rare: state1 refills first (libxpng.c:486-487)
-            const uint32_t n1 = m >> 1, n0 = m & 1u;
-            if (need) s = (s << 32) | (par ? w1 : (n1 ? w2 : w1));
-            rw = rw > n0 + n1 ? rw - (n0 + n1) : 0;
-            refill();
-            w1 = wring[(rw > 0 ? rw - 1 : 0) & 511u];
-            w2 = wring[(rw > 1 ? rw - 2 : 0) & 511u];
+    while (i >= 2 && (i & 7u)) XPNG_DEC_PAIR();  // down to a multiple of 8 symbols
+    // Main loop: straight-line blocks of 4 pair steps.  A lane packs its four symbols into one register; at the block end the
+    // pair's 8 bytes are interleaved (DPP swap + two v_perm) and leave as ONE 8-byte LDS store, and the ring flush is checked
+    // once: the per-step store / address arithmetic / loop bookkeeping (and the wait for that store at the top of every step)
+    // are gone from the dependent chain.
+    while (i >= 8) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t sym = 0;
+            bool need;
+            XPNG_DEC_ONE(sym, need);
+            acc = (acc << 8) | sym;
+            const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
+            if (m) XPNG_DEC_RENORM(need, m);
         }
-        if ((i & 511u) == 0) flush(i);
+        i -= 8;
+        const uint32_t oth = swap_pair(acc);
+        const uint32_t lo = __builtin_amdgcn_perm(oth, acc, 0x05010400u), hi = __builtin_amdgcn_perm(oth, acc, 0x07030602u);
+        if (lane == 0) *reinterpret_cast<uint2 *>(oring + (i & 511u)) = make_uint2(lo, hi);
+        if ((i & 511u) == 0) XPNG_DEC_FLUSH(i);
     }
+    while (i >= 2) XPNG_DEC_PAIR();
+#undef XPNG_DEC_PAIR
+#undef XPNG_DEC_RENORM
+#undef XPNG_DEC_ONE
+#undef XPNG_DEC_FLUSH
+#undef XPNG_DEC_REFILL
     XPNG_DSTAMP(2);
 }
 
