@@ -562,6 +562,227 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// The same chain on the SCALAR unit (single image: one wave per tile, latency is everything).  A step of the v_readlane form
+// above is ~16 VALU instructions of which five are dependent (readlane -> s_and -> v_cmp -> v_cndmask -> 64-bit shift ->
+// readlane), 45-60 ns.  Here the nine queue heads are 64-bit SGPR pairs s[40+2c : 41+2c] = (four symbols | marker bit 32) and the
+// step is nine scalar instructions, ~21 ns:
+//     m0 = 2 cur;  t = SGPR[40 + m0] (s_movrels_b64);  cur = t & 0xff;  t >>= 8;  t == 1 ? refill;  SGPR[40 + m0] = t;  out lane k = cur
+// The refill (once per four pops of a queue) takes the queue's next dword from lane c's register pair (w0, w1 <- its LDS ring)
+// by v_readlane; the LDS read that tops w1 up has eight pops of that queue to land.  The head registers live in VGPR lanes
+// between blocks of 64 steps (the compiler may use any SGPR between two asm statements), symbols > 8 (corrupt streams only)
+// are masked to 4 bits and index spare pairs s[58:71], so no register outside s[40:77] is ever touched.
+// Requires 4-byte aligned queue starts (k_dec_parse aligns them to 16).
+#define XPNG_WS(k)                                                                                                                  \
+    "s_lshl_b32 m0, %[cur], 1\n s_nop 0\n s_movrels_b64 s[74:75], s[40:41]\n s_and_b32 %[cur], s74, 0xff\n s_lshr_b64 s[74:75], s[74:75], 8\n" \
+    "s_cmp_eq_u64 s[74:75], 1\n s_cbranch_scc1 .Lwr%=_" #k "\n.Lwa%=_" #k ":\n s_movreld_b64 s[40:41], s[74:75]\n v_writelane_b32 %[vout], %[cur], " #k "\n"
+#define XPNG_WR(k)                                                                                                                  \
+    ".Lwr%=_" #k ":\n s_lshr_b32 s72, m0, 1\n s_nop 3\n v_readlane_b32 s74, %[w0], s72\n s_and_b32 s74, s74, 0x0f0f0f0f\n s_mov_b32 s75, 1\n"   \
+    "v_cmp_eq_u32 vcc, s72, %[lanev]\n s_and_saveexec_b64 s[76:77], vcc\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %[w0], %[w1]\n"               \
+    "v_and_b32 %[vt], 0x3ff, %[rd]\n v_add_u32 %[vt], %[vt], %[rbase]\n ds_read_b32 %[w1], %[vt]\n v_add_u32 %[rd], 4, %[rd]\n"           \
+    "s_mov_b64 exec, s[76:77]\n s_branch .Lwa%=_" #k "\n"
+__device__ inline void ctx_walk_salu(const uint8_t *__restrict__ base, uint32_t qs_in, uint32_t total, uint8_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    __shared__ __align__(16) uint8_t qring[9][1024];
+    const uint32_t qs = lane < 9 ? qs_in : 0;
+    const uint32_t qsa = qs & ~15u;
+    for (uint32_t c = 0; c < 9; c++) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, (int)c);
+        reinterpret_cast<uint4 *>(qring[c])[lane] = (reinterpret_cast<const uint4 *>(base + a) + lane)[0];  // 64 lanes x 16 B = both 512-byte units
+    }
+    __syncthreads();
+    uint32_t filled = 2;                      // units staged for this lane's queue
+    const uint32_t ql = lane < 9 ? lane : 0;  // lanes >= 9 alias queue 0's ring; nothing they hold is ever a real symbol
+    const uint32_t p0 = qs & 12u;
+    const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&qring[ql][p0]);
+    uint32_t qlo = lane < 9 ? (r0[0] & 0x0F0F0F0Fu) : 0u, qhi = 1u;
+    uint32_t w0 = r0[1], w1 = r0[2], rd = p0 + 12, vt, vout;
+    const uint32_t rbase = (uint32_t)(uintptr_t)&qring[ql][0];  // LDS byte address of this lane's ring (low 32 bits of the flat address)
+    uint32_t cur = 0;
+    for (uint32_t k = 0; k < total; k += 64) {
+        {   // stage one more 512-byte unit for every queue whose reads can reach the end of what is staged within this block
+            uint64_t m = __ballot(lane < 9 && rd + 96 >= filled * 512u);
+            if (m) {
+                __syncthreads();
+                while (m) {
+                    const int c = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, c);
+                    const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)filled, c);
+                    if (lane < 32) reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * 32 + lane] = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * 32];
+                    if ((int)lane == c) filled++;
+                }
+                __syncthreads();
+            }
+        }
+        asm volatile(
+            "s_mov_b32 s73, m0\n"
+        "v_readlane_b32 s40, %[qlo], 0\n v_readlane_b32 s41, %[qhi], 0\n"
+        "v_readlane_b32 s42, %[qlo], 1\n v_readlane_b32 s43, %[qhi], 1\n"
+        "v_readlane_b32 s44, %[qlo], 2\n v_readlane_b32 s45, %[qhi], 2\n"
+        "v_readlane_b32 s46, %[qlo], 3\n v_readlane_b32 s47, %[qhi], 3\n"
+        "v_readlane_b32 s48, %[qlo], 4\n v_readlane_b32 s49, %[qhi], 4\n"
+        "v_readlane_b32 s50, %[qlo], 5\n v_readlane_b32 s51, %[qhi], 5\n"
+        "v_readlane_b32 s52, %[qlo], 6\n v_readlane_b32 s53, %[qhi], 6\n"
+        "v_readlane_b32 s54, %[qlo], 7\n v_readlane_b32 s55, %[qhi], 7\n"
+        "v_readlane_b32 s56, %[qlo], 8\n v_readlane_b32 s57, %[qhi], 8\n"
+        "v_readlane_b32 s58, %[qlo], 9\n v_readlane_b32 s59, %[qhi], 9\n"
+        "v_readlane_b32 s60, %[qlo], 10\n v_readlane_b32 s61, %[qhi], 10\n"
+        "v_readlane_b32 s62, %[qlo], 11\n v_readlane_b32 s63, %[qhi], 11\n"
+        "v_readlane_b32 s64, %[qlo], 12\n v_readlane_b32 s65, %[qhi], 12\n"
+        "v_readlane_b32 s66, %[qlo], 13\n v_readlane_b32 s67, %[qhi], 13\n"
+        "v_readlane_b32 s68, %[qlo], 14\n v_readlane_b32 s69, %[qhi], 14\n"
+        "v_readlane_b32 s70, %[qlo], 15\n v_readlane_b32 s71, %[qhi], 15\n"
+        "s_nop 3\n"
+        XPNG_WS(0)
+        XPNG_WS(1)
+        XPNG_WS(2)
+        XPNG_WS(3)
+        XPNG_WS(4)
+        XPNG_WS(5)
+        XPNG_WS(6)
+        XPNG_WS(7)
+        XPNG_WS(8)
+        XPNG_WS(9)
+        XPNG_WS(10)
+        XPNG_WS(11)
+        XPNG_WS(12)
+        XPNG_WS(13)
+        XPNG_WS(14)
+        XPNG_WS(15)
+        XPNG_WS(16)
+        XPNG_WS(17)
+        XPNG_WS(18)
+        XPNG_WS(19)
+        XPNG_WS(20)
+        XPNG_WS(21)
+        XPNG_WS(22)
+        XPNG_WS(23)
+        XPNG_WS(24)
+        XPNG_WS(25)
+        XPNG_WS(26)
+        XPNG_WS(27)
+        XPNG_WS(28)
+        XPNG_WS(29)
+        XPNG_WS(30)
+        XPNG_WS(31)
+        XPNG_WS(32)
+        XPNG_WS(33)
+        XPNG_WS(34)
+        XPNG_WS(35)
+        XPNG_WS(36)
+        XPNG_WS(37)
+        XPNG_WS(38)
+        XPNG_WS(39)
+        XPNG_WS(40)
+        XPNG_WS(41)
+        XPNG_WS(42)
+        XPNG_WS(43)
+        XPNG_WS(44)
+        XPNG_WS(45)
+        XPNG_WS(46)
+        XPNG_WS(47)
+        XPNG_WS(48)
+        XPNG_WS(49)
+        XPNG_WS(50)
+        XPNG_WS(51)
+        XPNG_WS(52)
+        XPNG_WS(53)
+        XPNG_WS(54)
+        XPNG_WS(55)
+        XPNG_WS(56)
+        XPNG_WS(57)
+        XPNG_WS(58)
+        XPNG_WS(59)
+        XPNG_WS(60)
+        XPNG_WS(61)
+        XPNG_WS(62)
+        XPNG_WS(63)
+            "s_branch .Lwend%=\n"
+        XPNG_WR(0)
+        XPNG_WR(1)
+        XPNG_WR(2)
+        XPNG_WR(3)
+        XPNG_WR(4)
+        XPNG_WR(5)
+        XPNG_WR(6)
+        XPNG_WR(7)
+        XPNG_WR(8)
+        XPNG_WR(9)
+        XPNG_WR(10)
+        XPNG_WR(11)
+        XPNG_WR(12)
+        XPNG_WR(13)
+        XPNG_WR(14)
+        XPNG_WR(15)
+        XPNG_WR(16)
+        XPNG_WR(17)
+        XPNG_WR(18)
+        XPNG_WR(19)
+        XPNG_WR(20)
+        XPNG_WR(21)
+        XPNG_WR(22)
+        XPNG_WR(23)
+        XPNG_WR(24)
+        XPNG_WR(25)
+        XPNG_WR(26)
+        XPNG_WR(27)
+        XPNG_WR(28)
+        XPNG_WR(29)
+        XPNG_WR(30)
+        XPNG_WR(31)
+        XPNG_WR(32)
+        XPNG_WR(33)
+        XPNG_WR(34)
+        XPNG_WR(35)
+        XPNG_WR(36)
+        XPNG_WR(37)
+        XPNG_WR(38)
+        XPNG_WR(39)
+        XPNG_WR(40)
+        XPNG_WR(41)
+        XPNG_WR(42)
+        XPNG_WR(43)
+        XPNG_WR(44)
+        XPNG_WR(45)
+        XPNG_WR(46)
+        XPNG_WR(47)
+        XPNG_WR(48)
+        XPNG_WR(49)
+        XPNG_WR(50)
+        XPNG_WR(51)
+        XPNG_WR(52)
+        XPNG_WR(53)
+        XPNG_WR(54)
+        XPNG_WR(55)
+        XPNG_WR(56)
+        XPNG_WR(57)
+        XPNG_WR(58)
+        XPNG_WR(59)
+        XPNG_WR(60)
+        XPNG_WR(61)
+        XPNG_WR(62)
+        XPNG_WR(63)
+            ".Lwend%=:\n"
+        "v_writelane_b32 %[qlo], s40, 0\n v_writelane_b32 %[qhi], s41, 0\n"
+        "v_writelane_b32 %[qlo], s42, 1\n v_writelane_b32 %[qhi], s43, 1\n"
+        "v_writelane_b32 %[qlo], s44, 2\n v_writelane_b32 %[qhi], s45, 2\n"
+        "v_writelane_b32 %[qlo], s46, 3\n v_writelane_b32 %[qhi], s47, 3\n"
+        "v_writelane_b32 %[qlo], s48, 4\n v_writelane_b32 %[qhi], s49, 4\n"
+        "v_writelane_b32 %[qlo], s50, 5\n v_writelane_b32 %[qhi], s51, 5\n"
+        "v_writelane_b32 %[qlo], s52, 6\n v_writelane_b32 %[qhi], s53, 6\n"
+        "v_writelane_b32 %[qlo], s54, 7\n v_writelane_b32 %[qhi], s55, 7\n"
+        "v_writelane_b32 %[qlo], s56, 8\n v_writelane_b32 %[qhi], s57, 8\n"
+            "s_mov_b32 m0, s73\n"
+            : [qlo] "+v"(qlo), [qhi] "+v"(qhi), [w0] "+v"(w0), [w1] "+v"(w1), [rd] "+v"(rd), [vt] "=&v"(vt), [vout] "=&v"(vout), [cur] "+s"(cur)
+            : [rbase] "v"(rbase), [lanev] "v"(lane)
+            : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "vcc", "scc", "memory");
+        if (k + lane < total) out[k + lane] = (uint8_t)vout;
+    }
+}
+#undef XPNG_WS
+#undef XPNG_WR
+
 __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                  TileSel sel, const uint8_t *__restrict__ ctxsym,
                                                  uint8_t *__restrict__ nlseq) {
@@ -570,7 +791,7 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
     if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
     const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ctx_start[9]);
-    ctx_walk(ctxsym + t.pbase, lane < 9 ? d.ctx_start[lane] : 0, total, nlseq + t.pbase);
+    ctx_walk_salu(ctxsym + t.pbase, lane < 9 ? d.ctx_start[lane] : 0, total, nlseq + t.pbase);  // (k_dec_parse aligns the queue starts to 16 bytes)
 }
 
 // --------------------------------------------------------------------------------------------------
