@@ -43,7 +43,7 @@ template <bool BIG> struct WdLayout {
     static constexpr uint32_t CO_OFF = 4 * (FCN + 1), TAB = CO_OFF + (1u << CBITS);
 };
 // Alpha streams of mode 1 (pb 15, up to 256 symbols) use a denser form of the big layout: 16-bit cumulative counts
-// cum[0 .. N] (cum[N] = 2^pb; entries behind it 0xFFFF, which stops any scan), F = cum[sym + 1] - cum[sym], and 2^9 coarse
+// cum[0 .. N] (cum[N] = 2^pb; entries behind it 0x8000, which stops any scan), F = cum[sym + 1] - cum[sym], and 2^9 coarse
 // bytes (64-slot buckets): 1 KB instead of 2 KB of LDS per resident stream, the largest LDS holder of a pipelined batch.
 struct WdLayoutA {
     static constexpr uint32_t CBITS = 9, FCN = 256, RING = 64, REGN = 9;
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
         for (uint32_t i = lane; i <= WdLayout<false>::FCN; i += 64) gfc[i] = i < N ? fc[i] : 0xFFFFu;
     } else {
         uint16_t *gcu = reinterpret_cast<uint16_t *>(gt);
-        for (uint32_t i = lane; i <= WdLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < N ? fc[i] >> 16 : (i == N ? 1u << pb : 0xFFFFu));
+        // (entries behind cum[N] = 2^pb hold 0x8000: greater than any slot, and slot - entry keeps its 16-bit sign bit set)
+        for (uint32_t i = lane; i <= WdLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < N ? fc[i] >> 16 : (i == N ? 1u << pb : 0x8000u));
     }
     {   // coarse slot -> symbol
         const uint32_t sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         uint32_t *dst = reinterpret_cast<uint32_t *>(ltab + ts * TSTRIDE);
         if (jj >= total || sgpr(wdec[(uint64_t)jj * 10 + c].kind) != KIND) {
             // no chain in this slot: its lanes idle through the loop, but their table lookups must still terminate
-            for (uint32_t i = lane; i < LTAB / 4; i += 64) dst[i] = i < L::CO_OFF / 4 ? (BIG ? 0xFFFFFFFFu : 0xFFFFu) : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
+            // (big layout: cum[0] = 0, every other entry 0x8000: symbol 0 owns every slot)
+            for (uint32_t i = lane; i < LTAB / 4; i += 64) dst[i] = i < L::CO_OFF / 4 ? (BIG ? (i ? 0x80008000u : 0x80000000u) : 0xFFFFu) : 0u;  // every coarse byte names symbol 0, whose entry stops the scan
             continue;
         }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dtab + ((uint64_t)jj * 10 + c) * WD_TAB_MAX);
@@ -314,9 +316,45 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             cum = pick32(b3, c8, cum); nxt = pick32(b3, c9, nxt);
             F = nxt - cum; off = slot - cum;
         } else {
+            // slot -> symbol without a data-dependent scan (a wave waits for its slowest lane, and a 64-slot bucket of a skewed
+            // alphabet holds half a dozen narrow symbols: the serial scan cost 5-6 dependent LDS reads per cold step): the coarse
+            // byte names the symbol owning the bucket's first slot, the next eight cumulative counts come in ONE 16-byte read
+            // and are compared at once (packed 16-bit differences: cum is non-decreasing, so the count of "slot >= cum" is the
+            // position of the first set sign bit); buckets with more than seven boundaries (rare) go round again
+            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+            typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+            typedef __attribute__((address_space(3))) u32x4_a2 lds128u;
+            typedef uint32_t u32_a2 __attribute__((aligned(2)));
+            typedef __attribute__((address_space(3))) u32_a2 lds32u;
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
-            uint32_t c0 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym), c1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym + 2);
-            while (slot >= c1) { sym++; c0 = c1; c1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym + 2); }  // entries behind cum[N] stop it (0xFFFF)
+            const uint32_t slot2 = slot | (slot << 16);
+            auto count8 = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {  // how many of cum[from + 1 .. from + 8] are <= slot
+                const u32x4_a2 v = *(const lds128u *)(uintptr_t)(a_fc + 2 * from + 2);
+                uint32_t m[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t vq = v[q];  // (by value: __builtin_bit_cast of the vector ELEMENT expression reads element 0)
+                    const u16x2 d = __builtin_bit_cast(u16x2, slot2) - __builtin_bit_cast(u16x2, vq);
+                    m[q] = __builtin_bit_cast(uint32_t, d) & 0x80008000u;  // the two sign bits
+                }
+                // sign bits (bit 15 / 31 of m[q]) -> bit 2q (low half: value 2q) and bit 16 + 2q (high half: value 2q + 1)
+                uint32_t all = (m[0] >> 15) | (m[1] >> 13) | (m[2] >> 11) | (m[3] >> 9);
+                all = (all | (all >> 15)) & 0xFFu;
+                return (uint32_t)__builtin_ctz(all | 0x100u);
+            };
+            uint32_t t = count8(sym);
+            sym += t;
+            if (__ballot(t == 8)) {            // (uniform) a bucket with more than seven boundaries: second round
+                t = t == 8 ? count8(sym) : 0u;
+                sym += t;
+                if (__ballot(t == 8)) {        // still not there (dense alphabets, corrupt tables): plain scan, bounded by the sentinels
+                    uint32_t c1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym + 2);
+                    while (slot >= c1 && sym < 255u) { sym++; c1 = *(const lds16 *)(uintptr_t)(a_fc + 2 * sym + 2); }
+                }
+            }
+            sym = sym < 255u ? sym : 255u;
+            const uint32_t cc = *(const lds32u *)(uintptr_t)(a_fc + 2 * sym);
+            const uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
             F = c1 - c0; off = slot - c0;
         }
         if (!act) { F = ident; off = slot; }
