@@ -230,9 +230,11 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
         # decode as the reference times it (libxpng.c:967-985): the tile-size walk is part of the step, on the device
         sl["ctx"].decode_device_batch(level, sl["blob_ptrs"], lens_b, None, sl["back_ptrs"], t0, t1, stream=sh)
 
-    def timed(fn, reps):  # HIP events on the stream the kernels run on
+    def timed(fn, reps, warm=1):  # HIP events on the stream the kernels run on
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn(); torch.cuda.synchronize()
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
             fn()
@@ -244,7 +246,27 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
     # the roofline kernels run over the whole batch per launch (a single 4096^2 pass is ~30 us, i.e. launch-bound); timed
     # here, before the pipelined steps, with nothing else on the device
     if roofline_reps:
-        res["tr_ms"] = timed(lambda: ctx.transform_device_batch(rast_ptrs, t0, t1, stream=stream), roofline_reps)
+        # (a few untimed launches first: a leg may start on a GPU that idled through the previous leg's CPU baseline)
+        res["tr_ms"] = timed(lambda: ctx.transform_device_batch(rast_ptrs, t0, t1, stream=stream), roofline_reps, warm=8)
+    if single:
+        # ONE image of the workload, strictly serial, nothing else on the device (measured before the pipelined steps heat the
+        # part up: a chain-latency-bound launch sequence scales with the clock): on-device latency ...
+        reps = max(5, steps // 2)
+        res["enc_ms"] = timed(lambda: ctx.encode_device(level, rast_ptrs[0], blob_ptrs[0], t0, t1, stream=stream, sync=False), reps, warm=2)
+        res["dec_ms"] = timed(lambda: ctx.decode_device(level, blob_ptrs[0], n, None, back_ptrs[0], t0, t1, stream=stream), reps, warm=2)
+        if world == 1:
+            # ... and the wall time of the host-buffer entry points that xpng_store / xpng_load call (include/xpng_hip.h:
+            # xpnghip_encode_tiles / xpnghip_decode_tiles): host raster in, malloc()ed blobs out, PCIe both ways included
+            from xpng_amd import api
+            host_r = band.cpu().numpy()
+            blobs_h = api.encode_tiles(level, host_r)
+            assert blobs_h == d_blobs_all[0][:n].cpu().numpy().tobytes()
+            best_e = best_d = 1e9
+            for _ in range(5):
+                t_a = time.perf_counter(); api.encode_tiles(level, host_r); best_e = min(best_e, time.perf_counter() - t_a)
+                t_a = time.perf_counter(); back = api.decode_tiles(level, blobs_h, W, H, ch); best_d = min(best_d, time.perf_counter() - t_a)
+            assert (back == host_r).all()
+            res["api_enc_ms"], res["api_dec_ms"] = best_e * 1e3, best_d * 1e3
     # every pipeline slot allocates its decode workspace on first use: touch each once before the W warmup steps, so that a
     # small W still leaves no allocation inside the timed region (these P untimed steps are in addition to the W requested)
     for _ in range(len(slots)):
@@ -270,24 +292,6 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
                 raise SystemExit(f"rank {rank}: slot {si} image {bi} differs from the verified image")
     res.update(elapsed=elapsed, ms_per_step=elapsed / steps * 1e3, mpx_s=B * total_px * steps / elapsed / 1e6,
                hbm_in_use_gb=round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30, 1))
-    if single:
-        # ONE image of the workload, strictly serial, nothing else on the device: on-device latency ...
-        reps = max(3, steps // 2)
-        res["enc_ms"] = timed(lambda: ctx.encode_device(level, rast_ptrs[0], blob_ptrs[0], t0, t1, stream=stream, sync=False), reps)
-        res["dec_ms"] = timed(lambda: ctx.decode_device(level, blob_ptrs[0], n, None, back_ptrs[0], t0, t1, stream=stream), reps)
-        if world == 1:
-            # ... and the wall time of the host-buffer entry points that xpng_store / xpng_load call (include/xpng_hip.h:
-            # xpnghip_encode_tiles / xpnghip_decode_tiles): host raster in, malloc()ed blobs out, PCIe both ways included
-            from xpng_amd import api
-            host_r = band.cpu().numpy()
-            blobs_h = api.encode_tiles(level, host_r)
-            assert blobs_h == d_blobs_all[0][:n].cpu().numpy().tobytes()
-            best_e = best_d = 1e9
-            for _ in range(5):
-                t_a = time.perf_counter(); api.encode_tiles(level, host_r); best_e = min(best_e, time.perf_counter() - t_a)
-                t_a = time.perf_counter(); back = api.decode_tiles(level, blobs_h, W, H, ch); best_d = min(best_d, time.perf_counter() - t_a)
-            assert (back == host_r).all()
-            res["api_enc_ms"], res["api_dec_ms"] = best_e * 1e3, best_d * 1e3
     res["host_raster"] = band.cpu().numpy() if (world == 1 and rank == 0) else None
     for sl in slots:
         sl["ctx"].close()

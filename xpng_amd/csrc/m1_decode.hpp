@@ -1453,6 +1453,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                        (many_queues || getenv("XPNG_SPLIT"));
     const uint32_t jb = split ? n_big * B : 0;
     const uint32_t nostore = getenv("XPNG_DBG_NOSTORE") ? 1u : 0u;
+    // Occupancy limiter of the band reconstruction: 12 KB of unused LDS per wave keep it at ~10 waves per CU.  Its scattered
+    // 16-byte loads and stores (64 rows per instruction) fill the memory pipeline's queues, and the chain kernels of the other
+    // pipeline slots, which touch memory once per 8-step block, then wait for their words: decode-only rate at 3 slots
+    // 43 -> 51 Gpx/s, combined bench +4 % (XPNG_RECON_LDS_PAD=0 turns it off)
+    const size_t dbg_pad = getenv("XPNG_RECON_LDS_PAD") ? (size_t)atoi(getenv("XPNG_RECON_LDS_PAD")) : 12288;
     if (split) {
         if (!ws.side2) {
             if (hipStreamCreateWithFlags(&ws.side2, hipStreamNonBlocking) != hipSuccess ||
@@ -1462,14 +1467,18 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         }
         if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
         k_dec_walk_wide<<<(total - jb + 63) / 64, 64, 0, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
-        k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
+        // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
+        // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
+        if (getenv("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        else k_dec_walk<<<jb, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
             k_dec_resid<4, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<4><<<total - jb, 64, (size_t)max_w * 4 + 256, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
+            k_dec_recon_band<4><<<total - jb, 64, (size_t)max_w * 4 + 256 + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
         } else {
             k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<3><<<total - jb, 64, (size_t)max_w * 4 + 256, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
+            k_dec_recon_band<3><<<total - jb, 64, (size_t)max_w * 4 + 256 + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
     } else if (wide && !getenv("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
@@ -1479,13 +1488,13 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (wide) k_dec_resid<4, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<4><<<nt, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
+        if (band) k_dec_recon_band<4><<<nt, 64, (size_t)max_w * 4 + 256 + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
         if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<3><<<nt, 64, (size_t)max_w * 4 + 256, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0);
+        if (band) k_dec_recon_band<3><<<nt, 64, (size_t)max_w * 4 + 256 + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0);
         else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }

@@ -27,6 +27,7 @@ struct WDec {          // per (tile, stream) descriptor written by k_rans2_dec_p
     uint32_t words_off;  // byte offset of words[0] inside the tile blob
     uint64_t out_off;  // symbol destination, relative to ctxsym (c < 9) or asym (c == 9)
     uint32_t hot0, hot1;  // the two most probable symbols
+    uint32_t rsh;         // alpha layout: the coarse bytes are indexed by (cold rank >> rsh), see k_rans2_dec_prep
 };
 
 // Decode tables of one stream: fc[FCN + 1] dwords (F | cum << 16; entries >= N hold F = 0xFFFF, cum = 0, which stops any
@@ -152,12 +153,30 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
         // (entries behind cum[N] = 2^pb hold 0x8000: greater than any slot, and slot - entry keeps its 16-bit sign bit set)
         for (uint32_t i = lane; i <= WdLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < N ? fc[i] >> 16 : (i == N ? 1u << pb : 0x8000u));
     }
-    {   // coarse slot -> symbol
-        const uint32_t sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
+    // Alpha layout: the coarse bytes are indexed by the slot's COLD RANK (its position among the slots that belong to neither of
+    // the two hot symbols, which the chain resolves in registers).  A skewed alphabet squeezes its two hundred rare symbols into
+    // a few hundred slots: in slot space a 64-slot bucket of that region holds dozens of symbol boundaries, in rank space the
+    // whole region usually fits the 512 entries one slot apiece (rsh = 0) and the lookup is exact.
+    uint32_t rsh = 0, Ca = 0, Fa = 0, Cb = 0, Fb = 0;
+    if (!small) {
+        const uint32_t e0 = fc[hot0 & 255u], e1 = fc[hot1 & 255u];
+        Ca = e0 >> 16; Fa = e0 & 0xFFFFu;
+        if ((hot1 & 255u) != (hot0 & 255u)) { Cb = e1 >> 16; Fb = e1 & 0xFFFFu; }
+        if (Fb && Cb < Ca) { const uint32_t tc = Ca, tf = Fa; Ca = Cb; Fa = Fb; Cb = tc; Fb = tf; }  // a = the lower one
+        const uint32_t cold = (1u << pb) - Fa - Fb;
+        while ((cold >> rsh) > (1u << cbits)) rsh++;
+    }
+    {   // coarse (slot or cold rank) -> symbol
+        const uint32_t sh = small ? (pb > cbits ? pb - cbits : 0) : rsh, entries = small ? 1u << (pb - sh) : 1u << cbits;
         for (uint32_t g0 = lane * 4; g0 < entries; g0 += 256) {
             uint32_t pk = 0;
             for (uint32_t q = 0; q < 4; q++) {
-                const uint32_t s = (g0 + q) << sh;
+                uint32_t s = (g0 + q) << sh;
+                if (!small) {  // rank -> slot: step over the hot ranges
+                    if (s >= Ca) s += Fa;
+                    if (Fb && s >= Cb) s += Fb;
+                    s = s < (1u << pb) ? s : (1u << pb) - 1;
+                }
                 uint32_t lo = 0, hi = N - 1;  // largest index with cum <= s
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi + 1) >> 1;
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
         w.words_off = d.blk_off[c] + 12;
         w.out_off = out_off;
         w.hot0 = hot0 & 255u; w.hot1 = hot1 & 255u;
+        w.rsh = rsh;
         *wd = w;
     }
 }
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     const uintptr_t words_safe = live ? words : (uintptr_t)dtab;  // (idle lanes still issue the block loads: any readable address)
     uint8_t *out = (c < 9 ? ctxsym : asym) + (live ? wd->out_off : 0);
     const uint32_t n = live ? wd->n : 0, pb = live ? wd->pb : 12, nw = live ? wd->nw : 0;
-    const uint32_t npairs = n >> 1, mask = (1u << pb) - 1, csh = pb > (uint32_t)CBITS ? pb - CBITS : 0;
+    const uint32_t npairs = n >> 1, mask = (1u << pb) - 1;
     const uint32_t ident = 1u << pb;  // table entry (F = 2^pb, cum = 0): the step maps s to s, which is how an idle lane waits
     // LDS byte addresses
     const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + L::CO_OFF;
@@ -279,6 +299,10 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             hF0 = e0 & 0xFFFFu; hC0 = e0 >> 16; hF1 = e1 & 0xFFFFu; hC1 = e1 >> 16;
         }
     }
+    // alpha layout: cold rank of a slot = slot minus the hot ranges below it; the coarse bytes are indexed by rank >> rsh
+    const uint32_t rE0 = hC0 + hF0, rE1 = hC1 + hF1, rF1 = hs1 != hs0 ? hF1 : 0u;
+    const uint32_t rsh = (BIG && live) ? wd->rsh : 0u;
+    const bool exact = BIG && __ballot(rsh != 0) == 0;  // every stream of the wave resolves a cold slot with one table byte
     // Small layout (nl-context streams, at most 9 symbols): the cumulative counts c1..c9 live in registers and a step finds
     // its symbol by a binary search over them, instead of two dependent LDS reads and a data-dependent scan that the whole
     // wave waits for.  (c_i = 2^pb for i >= N.)
@@ -326,7 +350,9 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             typedef __attribute__((address_space(3))) u32x4_a2 lds128u;
             typedef uint32_t u32_a2 __attribute__((aligned(2)));
             typedef __attribute__((address_space(3))) u32_a2 lds32u;
-            sym = *(const lds8 *)(uintptr_t)(a_co + (slot >> csh));
+            const uint32_t rank = slot - (slot >= rE0 ? hF0 : 0u) - (slot >= rE1 ? rF1 : 0u);
+            const uint32_t ridx = rank >> rsh;
+            sym = *(const lds8 *)(uintptr_t)(a_co + (ridx < (1u << CBITS) ? ridx : (1u << CBITS) - 1));
             const uint32_t slot2 = slot | (slot << 16);
             auto count8 = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {  // how many of cum[from + 1 .. from + 8] are <= slot
                 const u32x4_a2 v = *(const lds128u *)(uintptr_t)(a_fc + 2 * from + 2);
@@ -342,9 +368,11 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
                 all = (all | (all >> 15)) & 0xFFu;
                 return (uint32_t)__builtin_ctz(all | 0x100u);
             };
-            uint32_t t = count8(sym);
+            const bool hotlane = h0 || h1;     // (resolved in registers below: its table result is not used)
+            uint32_t t = exact ? 0u : count8(sym);
+            t = hotlane ? 0u : t;
             sym += t;
-            if (__ballot(t == 8)) {            // (uniform) a bucket with more than seven boundaries: second round
+            if (!exact && __ballot(t == 8)) {  // (uniform) a bucket with more than seven boundaries: second round
                 t = t == 8 ? count8(sym) : 0u;
                 sym += t;
                 if (__ballot(t == 8)) {        // still not there (dense alphabets, corrupt tables): plain scan, bounded by the sentinels
@@ -356,6 +384,9 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             const uint32_t cc = *(const lds32u *)(uintptr_t)(a_fc + 2 * sym);
             const uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
             F = c1 - c0; off = slot - c0;
+            if (HOT) {  // lanes that landed in a hot symbol while another lane of the wave did not
+                sym = h0 ? hs0 : (h1 ? hs1 : sym); F = h0 ? hF0 : (h1 ? hF1 : F); off = h0 ? d0 : (h1 ? d1 : off);
+            }
         }
         if (!act) { F = ident; off = slot; }
         const uint32_t qlo = __builtin_amdgcn_alignbit(shi, slo, pb), qhi = shi >> pb;  // s >> pb
