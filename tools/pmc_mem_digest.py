@@ -25,9 +25,10 @@ best = {}
 for (k, g) in set(fe) | set(wr):
     if k not in best or g > best[k]: best[k] = g
 rows, tf, tw = [], 0.0, 0.0
-for k, g in sorted(best.items()):
-    f = fe.get((k, g), 0.0) * 1024 * 2   # KiB -> bytes, x2 (gfx950 wide-read correction)
-    w = wr.get((k, g), 0.0) * 1024
+for (k, g) in sorted(set(fe) | set(wr)):
+    if g * 7 < best[k]: continue         # a single-image launch of the same kernel (the decode tail splits its launches by
+    f = fe.get((k, g), 0.0) * 1024 * 2   # tile size class: both parts of such a split are batched launches and count)
+    w = wr.get((k, g), 0.0) * 1024       # KiB -> bytes; fetch x2 (gfx950 wide-read correction)
     tf += f; tw += w
     rows.append({"kernel": k, "workgroups": g, "fetch_bytes_corrected": int(f), "write_bytes": int(w), "bytes_per_px": round((f + w) / px, 3)})
 rows.sort(key=lambda r: -(r["fetch_bytes_corrected"] + r["write_bytes"]))

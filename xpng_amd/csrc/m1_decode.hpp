@@ -1220,27 +1220,13 @@ constexpr uint32_t RB_MAXW = 2048;  // seam buffer, pixels
 __device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-byte a + b (mod 256)
     return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
 }
+// predmode (wave-uniform): 0 = average (p2a), 1 = gradient (p3a), 2 = left (p1x), 3 = up (p1y) for interior pixels; row 0 always
+// predicts from the left and column 0 from above.  Modes 2 and 3 occur in gray tiles of mode 2 only (libxpng.c:890-895).
 template <int PXSZ>
-__global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
-                                                       TileSel sel, const uint32_t *__restrict__ resid,
-                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0) {
-    extern __shared__ uint32_t seam[];  // one row of the widest tile of the launch (bottom row of the band above)
-    const uint32_t j = j0 + blockIdx.x, lane = threadIdx.x & 63;
-    const DecTile *d = info + j;
-    const uint32_t type = d->type;
-    if (type == TILE_BAD) return;
-    const TileDesc t = tiles[vtile(sel, j)];
-    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
-    if (type == 0) {  // raw rows (libxpng.c:846)
-        const uint8_t *src = d->blob + 4;
-        const uint64_t row = (uint64_t)t.w * PXSZ;
-        for (uint64_t b = lane; b < row * t.h; b += 64) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
-        return;
-    }
-    const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
-    const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | (PXSZ == 4 ? (kw0 & 255u) << 24 : 0u);
-    const bool grad = (type >> 1) & 1;
-    const uint32_t *rs = resid + t.pbase;
+__device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__restrict__ dst, uint64_t bpr, const uint32_t *__restrict__ rs,
+                                                uint32_t first, int predmode, uint32_t *seam, uint32_t dbgflags) {
+    const uint32_t lane = threadIdx.x & 63;
+    const bool grad = predmode == 1;
     const int32_t w = (int32_t)t.w;
     typedef uint32_t u32x4_a4r __attribute__((ext_vector_type(4), aligned(4)));
     for (uint32_t yb = 0; yb < t.h; yb += 64) {
@@ -1284,6 +1270,8 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
                     const int lg = (int)((prev >> 8) & 255u), ug = (int)((nU >> 8) & 255u), ulg = (int)((nUL >> 8) & 255u);
                     pred = pe | (((uint32_t)(((lg + ug) * 3 - 2 * ulg + 2) >> 2) & 255u) << 8);
                 }
+                pred = predmode == 2 ? prev : pred;
+                pred = predmode == 3 ? nU : pred;
                 pred = y == 0 ? prev : pred;   // row 0 predicts from the left,
                 pred = x == 0 ? nU : pred;     // column 0 from above (libxpng.c:805-810)
                 uint32_t px = (swar_add8(rw, pred) & 0x00FFFFFFu) | (rw & 0xFF000000u);  // alpha travels in the residual word
@@ -1319,6 +1307,28 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
           }
         }
     }
+}
+
+template <int PXSZ>
+__global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
+                                                       TileSel sel, const uint32_t *__restrict__ resid,
+                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0) {
+    extern __shared__ uint32_t seam[];  // one row of the widest tile of the launch (bottom row of the band above)
+    const uint32_t j = j0 + blockIdx.x, lane = threadIdx.x & 63;
+    const DecTile *d = info + j;
+    const uint32_t type = d->type;
+    if (type == TILE_BAD) return;
+    const TileDesc t = tiles[vtile(sel, j)];
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
+    if (type == 0) {  // raw rows (libxpng.c:846)
+        const uint8_t *src = d->blob + 4;
+        const uint64_t row = (uint64_t)t.w * PXSZ;
+        for (uint64_t b = lane; b < row * t.h; b += 64) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+        return;
+    }
+    const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
+    const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | (PXSZ == 4 ? (kw0 & 255u) << 24 : 0u);
+    recon_band_core<PXSZ>(t, dst, bpr, resid + t.pbase, first, (int)((type >> 1) & 1), seam, dbgflags);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -374,6 +374,41 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
     }
 }
 
+// The same for batches: ONE wavefront per tile sweeping 64-row bands (recon_band_core, m1_decode.hpp: lane = row, U by DPP, byte-
+// parallel predictors, 16-byte residual loads and 12-byte pixel stores), as mode 1 uses; the multi-wave form above hands rows
+// from wave to wave through LDS and progress counters, which is right for one image and 4x slower per tile in a batch.
+__global__ __launch_bounds__(64) void k_m2_dec_recon_band(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                          const uint32_t *__restrict__ resid, uint8_t *const *__restrict__ rasters, uint64_t bpr) {
+    extern __shared__ uint32_t seam[];
+    const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
+    const M2DecTile *d = info + j;
+    const uint32_t kind = d->kind;
+    if (kind == M2_KIND_BAD) return;
+    const TileDesc t = tiles[vtile(sel, j)];
+    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * 3;
+    const uint64_t row = (uint64_t)t.w * 3;
+    if (kind == 0 || kind == 3 || kind == 4) {  // raw rows (libxpng.c:941), raw gray (875-878), single colour (916-927)
+        const uint8_t *src = d->blob + 4;
+        for (uint64_t b = lane; b < row * t.h; b += 64) {
+            const uint64_t y = b / row, o = b - y * row;
+            dst[y * bpr + o] = kind == 0 ? src[b] : kind == 3 ? src[y * t.w + o / 3] : src[o % 3];
+        }
+        return;
+    }
+    const uint32_t w0 = ld32u(d->blob + 8);  // head of b: first pixel, MSB first
+    uint32_t first;
+    int predmode;
+    if (kind == 2) {
+        const uint32_t g = w0 >> 24;
+        first = g | (g << 8) | (g << 16);
+        predmode = d->m == 0 ? 2 : d->m == 1 ? 3 : d->m == 2 ? 0 : 1;  // p1x, p1y, p2a, p3a (libxpng.c:890-895)
+    } else {
+        first = ((w0 >> 24) & 255u) | (((w0 >> 16) & 255u) << 8) | (((w0 >> 8) & 255u) << 16);
+        predmode = (int)((d->m >> 1) & 1);
+    }
+    recon_band_core<3>(t, dst, bpr, resid + t.pbase, first, predmode, seam, 0u);
+}
+
 inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t total, const M2DecTile *d_info2, const TileDesc *d_tiles,
                           TileSel sel, const M2Blk *d_blk2, const uint16_t *d_tabs2, uint8_t *d_scratch2, const uint64_t *d_sbase2,
                           hipStream_t s, std::string &err);  // rans1_wide_dec.hpp
@@ -399,7 +434,9 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     k_m2_dec_resid<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
-    k_m2_dec_recon<<<total, rthreads, rlds, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+    const bool wide_recon = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * M2_STREAMS > 2048 || getenv("XPNG_WIDE_RANS")) && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON");
+    if (wide_recon) k_m2_dec_recon_band<<<total, 64, (size_t)max_w * 4 + 256, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr);
+    else k_m2_dec_recon<<<total, rthreads, rlds, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, free_ew);
     if (hipGetLastError() != hipSuccess) { err = "mode-2 decode kernel launch failed"; return 1; }
     return 0;
 }

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     const WDec *wd = wdec + (uint64_t)(live ? j : 0) * M2_SLOTS + slot;
     live = live && wd->kind == KIND;
     const uintptr_t words = live ? (uintptr_t)info[j].blob + wd->words_off : 0;
+    const uintptr_t words_safe = live ? words : (uintptr_t)dtab;  // (idle lanes still issue the block loads: any readable address)
     uint8_t *out = scratch2 + (live ? wd->out_off : 0);
     const uint32_t n = live ? wd->n : 0, pb = live ? wd->pb : 14, nw = live ? wd->nw : 0;
     const uint32_t pairs = n >> 1, mask = (1u << pb) - 1, csh = pb > CBITS ? pb - CBITS : 0;
@@ -168,7 +169,6 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     uint32_t fa0 = 0, fhi = 0, fsh = 0;
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     uint32_t qx = 0;
-    bool inflight = false;
     uint32_t wi = 0;                          // ring slot of w1 = words[rw]; w2 = words[rw + 1] sits 4 bytes above (mirror after the last slot)
     uint32_t w1, w2;
     auto fetch_w = [&]() __attribute__((always_inline)) {
@@ -238,48 +238,39 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
             if (tail) out[n - 1] = (uint8_t)sym;
         }
         rw += (wi - wi0) & (RING - 1);
-        if (inflight) {
+        {   // in-flight words land (unconditional, like the request below: fhi == 0 when nothing was requested)
             const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, PER > 4 ? q1.x : qx, q1.y, q1.z, q1.w, qx};
 #pragma unroll
             for (int i = 0; i < (int)PER; i++) {
                 const uint32_t a = fa0 + (uint32_t)i;
                 if (a < fhi) *ring_w(a) = __builtin_amdgcn_alignbyte(dw[i + 1], dw[i], fsh);
             }
-            inflight = false;
         }
         *(lds32 *)(uintptr_t)(a_ring + 4 * RING) = *ring_w(0);
         if (tb < pairs + (n & 1u) && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * tb) = *(const lds128 *)(uintptr_t)a_ob;
         hi = hif;
-        {   // request the words above: keep the ring at most RING ahead of the cursor, at most 2 PER words per boundary
+        {   // request the words above: keep the ring at most RING ahead of the cursor, at most 2 PER words per boundary.
+            // The loads are issued on EVERY boundary, from word 0 when there is nothing to fetch (fhi = 0 then keeps the landing
+            // from writing): a branch around them makes the compiler load into temporaries and copy those into the loop-carried
+            // registers at once - a wait for loads it has just issued, once per block (the cure the v2 chains already had).  A
+            // request near the top of the stream reads up to PER + 1 dwords from its first word, i.e. at most 36 bytes past the
+            // block: inside the 64 readable bytes every blob buffer carries behind its contents (include/xpng_hip.h).
             uint32_t want = hi + 2 * PER;
             const uint32_t room = rw + RING;
             want = want < room ? want : room;
             want = want < nw ? want : nw;
-            if (want > hi) {
-                const uint32_t a0 = hi + PER * par;
-                if (a0 < want) {
-                    const uintptr_t A = words + 4ull * a0;
-                    if (a0 + PER < nw) {  // PER + 1 dwords from the aligned address below: all inside the block's words
-                        const gptr32 p = (gptr32)(A & ~(uintptr_t)3);
-                        const u32x4_a4 v0 = *(gptr128)p;
-                        q0 = make_uint4(v0.x, v0.y, v0.z, v0.w);
-                        if (PER > 4) { const u32x4_a4 v1 = *(gptr128)(p + 4); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w); }
-                        qx = p[PER];
-                        fsh = (uint32_t)(A & 3);
-                    } else {              // the last words of the block (nothing may follow them in the caller's buffer): one by one
-                        uint32_t dwv[8];
-#pragma unroll
-                        for (int i = 0; i < 8; i++) dwv[i] = (i < (int)PER && a0 + (uint32_t)i < nw) ? gld32u(A + 4ull * (uint32_t)i) : 0u;
-                        q0 = make_uint4(dwv[0], dwv[1], dwv[2], dwv[3]);
-                        if (PER > 4) q1 = make_uint4(dwv[4], dwv[5], dwv[6], dwv[7]);
-                        qx = PER > 4 ? 0u : dwv[4];
-                        fsh = 0;
-                    }
-                    fa0 = a0; fhi = want;
-                    inflight = true;
-                }
-                hif = want;
-            }
+            const bool any = want > hi;
+            const uint32_t a0r = hi + PER * par;
+            const bool req = any && a0r < want;
+            const uint32_t a0 = req ? a0r : 0u;
+            const uintptr_t A = words_safe + 4ull * a0;
+            const gptr32 p = (gptr32)(A & ~(uintptr_t)3);
+            const u32x4_a4 v0 = *(gptr128)p;
+            q0 = make_uint4(v0.x, v0.y, v0.z, v0.w);
+            if (PER > 4) { const u32x4_a4 v1 = *(gptr128)(p + 4); q1 = make_uint4(v1.x, v1.y, v1.z, v1.w); }
+            qx = p[PER];
+            fa0 = a0; fhi = req ? want : 0u; fsh = (uint32_t)(A & 3);
+            hif = any ? want : hif;
         }
     }
 }
