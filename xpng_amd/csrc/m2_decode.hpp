@@ -257,7 +257,8 @@ __global__ __launch_bounds__(64) void k_m2_dec_walk(const M2DecTile *__restrict_
     if (d.kind != 1) return;
     const uint32_t tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
-    ctx_walk(scratch2 + sbase2[tile], lane < 9 ? (uint32_t)m2_off_stream(t.n, lane) : 0, sgpr(d.coded), nlseq + t.pbase);
+    // (the nine context streams start at multiples of 256 bytes inside the tile's scratch: the scalar-unit walk applies)
+    ctx_walk_salu(scratch2 + sbase2[tile], lane < 9 ? (uint32_t)m2_off_stream(t.n, lane) : 0, sgpr(d.coded), nlseq + t.pbase);
 }
 
 // --------------------------------------------------------------------------------------------------
