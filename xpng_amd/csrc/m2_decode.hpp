@@ -110,11 +110,12 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
                                                      uint32_t s_first, uint32_t s_count, const M2Blk *__restrict__ blk,
                                                      const uint16_t *__restrict__ tabs, uint8_t *__restrict__ scratch2,
                                                      const uint64_t *__restrict__ sbase2) {
-    __shared__ uint8_t coarse[1 << (MAXPB - 3)];  // symbol owning slot (i << 3): start of a short forward scan (8x less LDS than a
-                                                    // full slot table, which is what bounds the number of resident chains per CU)
+    // per group of 8 slots: (F | cum << 16, symbol) of the symbol owning slot (g << 3): one LDS read resolves a cold slot whose
+    // group lies inside one symbol's range, else a short forward scan over fc[] follows (as k_rans2_decode)
+    __shared__ uint2 coarse[1 << (MAXPB - 3)];
     __shared__ uint32_t fc[256];
     __shared__ uint32_t wring[512];
-    __shared__ uint8_t oring[512];
+    __shared__ __align__(8) uint8_t oring[512];
     const uint32_t j = blockIdx.x / s_count, slot = s_first + blockIdx.x % s_count, lane = threadIdx.x & 63, par = lane & 1;
     const M2DecTile d = info[j];
     if (!((d.kind == 1 && slot < 17) || (d.kind == 2 && slot == 17))) return;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
                 if ((fc[mid] >> 16) <= s) lo = mid; else hi = mid - 1;
             }
             while (lo > 0 && (fc[lo] & 0xFFFF) == 0) lo--;  // only reachable on corrupt tables
-            coarse[g] = (uint8_t)lo;
+            coarse[g] = make_uint2(fc[lo], lo);
         }
     }
     __syncthreads();
@@ -193,60 +194,92 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
     for (uint32_t i = lane; i < ring_hi; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
     __syncthreads();
     rw = sgpr(rw); ring_hi = sgpr(ring_hi);
-    auto refill = [&]() {
-        if (ring_hi < nw && rw + 128 > ring_hi) {
-            const uint32_t new_hi = ring_hi + 256 < nw ? ring_hi + 256 : nw;
-            __syncthreads();
-            for (uint32_t i = ring_hi + lane; i < new_hi; i += 64) wring[i & 511u] = ld32u(words + 4ull * i);
-            ring_hi = new_hi;
-            __syncthreads();
-        }
-    };
-    auto flush = [&](uint32_t base, uint32_t hi) {
-        __syncthreads();
-        for (uint32_t i = base + lane; i < hi; i += 64) out[i] = oring[i & 511u];
-        __syncthreads();
-    };
-    auto decode_one = [&](uint32_t &sym) {
-        const uint32_t slt = (uint32_t)s & mask;
-        const uint32_t d0 = slt - C0, d1 = slt - C1;
-        const bool hit0 = d0 < F0, hit1 = d1 < F1;
-        uint32_t F, offv;
-        if (__ballot(!(hit0 || hit1)) == 0) { F = hit0 ? F0 : F1; offv = hit0 ? d0 : d1; sym = hit0 ? sym0 : sym1; }
-        else {
-            sym = coarse[slt >> 3];
-            uint32_t e = fc[sym];
-            while (slt - (e >> 16) >= (e & 0xFFFF) && sym + 1 < Nnom) e = fc[++sym];  // walk to the symbol whose [cum, cum+F) holds the slot
-            F = e & 0xFFFF; offv = slt - (e >> 16);
-        }
-        return (uint64_t)F * (s >> pb) + offv;
-    };
+    // (step pieces as macros, not lambdas: see k_rans2_decode - closures used from several loops end up in scratch memory)
+#define XPNG_D1_REFILL()                                                                                              \
+    do {                                                                                                              \
+        if (ring_hi < nw && rw + 128 > ring_hi) {                                                                     \
+            const uint32_t new_hi_ = ring_hi + 256 < nw ? ring_hi + 256 : nw;                                         \
+            __syncthreads();                                                                                          \
+            for (uint32_t i_ = ring_hi + lane; i_ < new_hi_; i_ += 64) wring[i_ & 511u] = ld32u(words + 4ull * i_);   \
+            ring_hi = new_hi_;                                                                                        \
+            __syncthreads();                                                                                          \
+        }                                                                                                             \
+    } while (0)
+#define XPNG_D1_FLUSH(base, hi)                                                                                       \
+    do {                                                                                                              \
+        __syncthreads();                                                                                              \
+        for (uint32_t i_ = (base) + lane; i_ < (hi); i_ += 64) out[i_] = oring[i_ & 511u];                            \
+        __syncthreads();                                                                                              \
+    } while (0)
+#define XPNG_D1_ONE(sym)                                                                                              \
+    do {                                                                                                              \
+        const uint32_t slt_ = (uint32_t)s & mask;                                                                     \
+        const uint32_t d0_ = slt_ - C0, d1_ = slt_ - C1;                                                              \
+        const bool hit0_ = d0_ < F0, hit1_ = d1_ < F1;                                                                \
+        uint32_t F_, off_;                                                                                            \
+        if (__ballot(!(hit0_ || hit1_)) == 0) { F_ = hit0_ ? F0 : F1; off_ = hit0_ ? d0_ : d1_; sym = hit0_ ? sym0 : sym1; } \
+        else {                                                                                                        \
+            const uint2 cg_ = coarse[slt_ >> 3];                                                                      \
+            sym = cg_.y;                                                                                              \
+            uint32_t e_ = cg_.x;                                                                                      \
+            while (slt_ - (e_ >> 16) >= (e_ & 0xFFFF) && sym + 1 < Nnom) e_ = fc[++sym];                              \
+            F_ = e_ & 0xFFFF; off_ = slt_ - (e_ >> 16);                                                               \
+        }                                                                                                             \
+        s = (uint64_t)F_ * (s >> pb) + off_;                                                                          \
+    } while (0)
+    // state0 refills first (libxpng.c:295-296); the cursor stops at the end of the block
+#define XPNG_D1_RENORM(need, m)                                                                                       \
+    do {                                                                                                              \
+        const uint32_t n0_ = (m) & 1u, n1_ = (m) >> 1;                                                                \
+        const uint32_t wsel_ = par ? (n0_ ? w2 : w1) : w1;                                                            \
+        if (need) s = (s << 32) | wsel_;                                                                              \
+        rw = rw + n0_ + n1_ < nw ? rw + n0_ + n1_ : nw;                                                               \
+        XPNG_D1_REFILL();                                                                                             \
+        w1 = wring[rw & 511u];                                                                                        \
+        w2 = wring[(rw + 1) & 511u];                                                                                  \
+    } while (0)
     const uint32_t pairs = sgpr(n >> 1);
     uint32_t w1 = wring[rw & 511u], w2 = wring[(rw + 1) & 511u];
-    uint32_t flushed = 0;
-    for (uint32_t k = 0; k < pairs; k++) {
+    uint32_t flushed = 0, k = 0;
+    // straight-line blocks of 4 pair steps (8 symbols): a lane packs its four symbols, the pair's 8 bytes are interleaved by a DPP
+    // swap + two v_perm and leave as one 8-byte LDS store; the flush is checked once per block (2 k is a multiple of 8 here)
+    for (; k + 4 <= pairs; k += 4) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t sym = 0;
+            XPNG_D1_ONE(sym);
+            acc |= sym << (8 * u);
+            const bool need = s < RANS_L;
+            const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
+            if (m) XPNG_D1_RENORM(need, m);
+        }
+        const uint32_t oth = swap_pair(acc);
+        const uint32_t lo = __builtin_amdgcn_perm(oth, acc, 0x05010400u), hi = __builtin_amdgcn_perm(oth, acc, 0x07030602u);
+        if (lane == 0) *reinterpret_cast<uint2 *>(oring + ((2 * k) & 511u)) = make_uint2(lo, hi);
+        if (((2 * k + 8) & 511u) == 0) { XPNG_D1_FLUSH(flushed, 2 * k + 8); flushed = 2 * k + 8; }
+    }
+    for (; k < pairs; k++) {
         uint32_t sym = 0;
-        s = decode_one(sym);
+        XPNG_D1_ONE(sym);
         const bool need = s < RANS_L;
         const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
         if (lane < 2) oring[(2 * k + par) & 511u] = (uint8_t)sym;
-        if (m) {  // state0 refills first (libxpng.c:295-296); the cursor stops at the end of the block
-            const uint32_t n0 = m & 1u, n1 = m >> 1;
-            if (need) s = (s << 32) | (par ? (n0 ? w2 : w1) : w1);
-            rw = rw + n0 + n1 < nw ? rw + n0 + n1 : nw;
-            refill();
-            w1 = wring[rw & 511u];
-            w2 = wring[(rw + 1) & 511u];
-        }
-        if (((2 * k + 2) & 511u) == 0) { flush(flushed, 2 * k + 2); flushed = 2 * k + 2; }
+        if (m) XPNG_D1_RENORM(need, m);
+        if (((2 * k + 2) & 511u) == 0) { XPNG_D1_FLUSH(flushed, 2 * k + 2); flushed = 2 * k + 2; }
     }
     if (n & 1) {  // libxpng.c:300
         uint32_t sym = 0;
-        (void)decode_one(sym);
+        XPNG_D1_ONE(sym);
         if (lane == 0) oring[(n - 1) & 511u] = (uint8_t)sym;
     }
-    flush(flushed, n);
+    XPNG_D1_FLUSH(flushed, n);
+#undef XPNG_D1_RENORM
+#undef XPNG_D1_ONE
+#undef XPNG_D1_FLUSH
+#undef XPNG_D1_REFILL
 }
+
 
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_m2_dec_walk(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,

@@ -239,15 +239,26 @@ __global__ __launch_bounds__(64) void k_rans1_encode(const TileDesc *__restrict_
     uint64_t s = RANS_L;
     uint32_t cnt = 0, flushed = 0;
     uint32_t *w = out + 4;
+    // The recurrence runs BACKWARDS over the symbols; otherwise the structure of the v2 encoder (rans2_encode_block): straight-line
+    // double blocks of 8 steps, the 8 symbols of a block = one unaligned 8-byte LDS read issued two blocks ahead, its four table
+    // entries read one block ahead, the spill handling behind a wave-uniform branch, ring flush and unit rotation checked once
+    // per 128 steps.  The symbol ring (2 KB, 1 KB units, the stream's 16-byte phase kept) is filled downwards; its first 16
+    // bytes are mirrored behind its end so that a window read never wraps.
     const uint8_t *inA = reinterpret_cast<const uint8_t *>((uintptr_t)in & ~(uintptr_t)15);
     const uint32_t p0 = sgpr((uint32_t)((uintptr_t)in & 15));
     const uint4 *src = reinterpret_cast<const uint4 *>(inA) + lane;
+    __shared__ __align__(16) uint8_t smirror[16];
+    static_assert(sizeof(sring) == 2048, "ring size");
+    auto put_unit = [&](int32_t unit, const uint4 &v) __attribute__((always_inline)) {
+        reinterpret_cast<uint4 *>(sring)[(unit & 1) * 64 + lane] = v;
+        if ((unit & 1) == 0 && lane == 0) *reinterpret_cast<uint4 *>(smirror) = v;
+    };
     int32_t lo_unit = (int32_t)sgpr((p0 + n - 1) >> 10);  // lowest unit staged; units lo_unit and lo_unit+1 (if it exists) are in the ring
-    reinterpret_cast<uint4 *>(sring)[(lo_unit & 1) * 64 + lane] = src[lo_unit * 64];
-    if (lo_unit > 0) { lo_unit--; reinterpret_cast<uint4 *>(sring)[(lo_unit & 1) * 64 + lane] = src[lo_unit * 64]; }
+    put_unit(lo_unit, src[lo_unit * 64]);
+    if (lo_unit > 0) { lo_unit--; put_unit(lo_unit, src[lo_unit * 64]); }
     uint4 pre = lo_unit > 0 ? src[(lo_unit - 1) * 64] : make_uint4(0, 0, 0, 0);
     __syncthreads();
-    auto put = [&](const EncSym &e) {
+    auto put = [&](const EncSym &e) __attribute__((always_inline)) {
         const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
         const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
         const uint64_t q = __umul64hi(s, rcp) >> rsh;
@@ -255,47 +266,90 @@ __global__ __launch_bounds__(64) void k_rans1_encode(const TileDesc *__restrict_
     };
     const uint32_t pairs = sgpr(n >> 1);
     if (n & 1) { if (!par) put(tab[in[n - 1]]); }  // libxpng.c:218-225: no spill test on the odd tail
-    int32_t pos = (int32_t)(p0 + 2 * pairs) - 2;  // ring position of the even symbol of the next pair (uniform); may run below p0
-    auto next_sym = [&]() -> uint32_t {
-        if (lo_unit > 0 && pos < lo_unit * 1024 + 8) {  // uniform: rotate the prefetched lower unit in
-            __syncthreads();
-            lo_unit--;
-            reinterpret_cast<uint4 *>(sring)[(lo_unit & 1) * 64 + lane] = pre;
-            if (lo_unit > 0) pre = src[(lo_unit - 1) * 64];
-            __syncthreads();
-        }
-        const uint32_t sy = sring[(uint32_t)(pos + (int32_t)par) & 2047u];
-        pos -= 2;
-        return sy;
-    };
-    auto step = [&](const EncSym &e) {
+    auto step = [&](const EncSym &e) __attribute__((always_inline)) {
         const uint32_t freq = e.freq_shift & 0xFFFF;
         const bool emit = (uint32_t)(s >> 32) >= (freq << thr_shift);
         const uint32_t m = sgpr((uint32_t)__ballot(emit) & 3u);  // bit1: state1 spills (first), bit0: state0
-        const uint32_t e1 = m >> 1;
-        if (emit) {
-            if (lane < 2) ring[(cnt + (par ? 0u : e1)) & 511u] = (uint32_t)s;
-            s >>= 32;
+        if (m) {  // uniform
+            const uint32_t e1 = m >> 1;
+            if (emit) {
+                if (lane < 2) ring[(cnt + (par ? 0u : e1)) & 511u] = (uint32_t)s;
+                s >>= 32;
+            }
+            cnt += e1 + (m & 1u);
         }
-        cnt += e1 + (m & 1u);
         put(e);
-        if (cnt - flushed >= 256) {  // uniform
-            __syncthreads();
-            for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
-            flushed += 256;
-            __syncthreads();
-        }
     };
-    {
-        EncSym ea = tab[next_sym()], eb = tab[next_sym()], ec = tab[next_sym()];
-        uint32_t k = 0;
-        for (; k + 3 <= pairs; k += 3) {
-            step(ea); ea = tab[next_sym()];
-            step(eb); eb = tab[next_sym()];
-            step(ec); ec = tab[next_sym()];
+    auto flush256 = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        for (uint32_t i = lane; i < 256; i += 64) w[flushed + i] = ring[(flushed + i) & 511u];
+        flushed += 256;
+        __syncthreads();
+    };
+    auto rotate = [&]() __attribute__((always_inline)) {  // bring the prefetched lower unit in
+        __syncthreads();
+        lo_unit--;
+        put_unit(lo_unit, pre);
+        if (lo_unit > 0) pre = src[(lo_unit - 1) * 64];
+        __syncthreads();
+    };
+    // (the mirror lives right behind the ring: one contiguous 2064-byte object for the unaligned window reads)
+    typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+    auto window = [&](int32_t pos) -> u32x2_a1 {  // ring bytes [pos, pos + 8)
+        const uint32_t a = (uint32_t)pos & 2047u;
+        const u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(sring + a);
+        if (a <= 2040u) return v;
+        // the read crossed the end of the ring: splice in the mirror of its first bytes (rare: 7 of 2048 positions)
+        uint8_t tmp[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) tmp[q] = (a + q) < 2048u ? sring[a + q] : smirror[a + q - 2048u];
+        u32x2_a1 r;
+        r.x = tmp[0] | tmp[1] << 8 | tmp[2] << 16 | (uint32_t)tmp[3] << 24; r.y = tmp[4] | tmp[5] << 8 | tmp[6] << 16 | (uint32_t)tmp[7] << 24;
+        return r;
+    };
+    const uint32_t bsh = 8u * par;
+    // step u of a block (u = 0..3, downwards) codes the pair whose even symbol is byte 6 - 2u of the block's window
+    auto entry = [&](const u32x2_a1 &Wn, int u) -> EncSym {
+        const uint32_t d = u < 2 ? Wn.y : Wn.x;
+        const uint32_t sy = (d >> (bsh + 16u * (uint32_t)(1 - (u & 1)))) & 255u;
+        return tab[sy];
+    };
+    int32_t pos = (int32_t)(p0 + 2 * pairs) - 2;  // ring position of the even symbol of the next pair (uniform); may run below p0
+    const uint32_t n8 = pairs >> 3;
+    uint32_t db = 0;
+    if (n8) {
+        // block A covers ring bytes [pos - 6, pos + 2), block B the eight below, ...
+        u32x2_a1 Wa = window(pos - 6), Wb = window(pos - 14);
+        EncSym Ea[4], Eb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) Ea[u] = entry(Wa, u);
+        while (db < n8) {
+            if (cnt - flushed >= 256) flush256();
+            if (lo_unit > 0 && pos - 320 < lo_unit * 1024) rotate();
+            const uint32_t stop = sgpr(db + 16 < n8 ? db + 16 : n8);
+#pragma unroll 1
+            for (; db < stop; db++) {
+                Wa = window(pos - 22);
+#pragma unroll
+                for (int u = 0; u < 4; u++) Eb[u] = entry(Wb, u);
+#pragma unroll
+                for (int u = 0; u < 4; u++) step(Ea[u]);
+                Wb = window(pos - 30);
+#pragma unroll
+                for (int u = 0; u < 4; u++) Ea[u] = entry(Wa, u);
+#pragma unroll
+                for (int u = 0; u < 4; u++) step(Eb[u]);
+                pos -= 16;
+            }
         }
-        if (k < pairs) { step(ea); ea = eb; k++; }
-        if (k < pairs) { step(ea); k++; }
+    }
+    // ---- tail: fewer than 8 pair steps, one at a time straight from the ring
+    __syncthreads();
+    if (cnt - flushed >= 256) flush256();
+    if (lo_unit > 0 && pos - 64 < lo_unit * 1024) rotate();
+    for (uint32_t k = n8 * 8; k < pairs; k++) {
+        step(tab[sring[(uint32_t)(pos + (int32_t)par) & 2047u]]);
+        pos -= 2;
     }
     __syncthreads();
     for (uint32_t i = flushed + lane; i < cnt; i += 64) w[i] = ring[i & 511u];
