@@ -132,10 +132,13 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     const uint8_t *in = BIG ? planes + 4 * plane_stride + t->pbase : sc + off_ctx(t->n, (int)c);  // 16-byte aligned; symbol i at in[i + SH]
     const uint32_t n = !live ? 0 : BIG ? t->n - 1 : ctx_n[(uint64_t)tile * 9 + c];
     const uint32_t mysteps = (n + 1 - par) >> 1;  // state0 codes ceil(n/2) symbols, state1 floor(n/2)
-    uint32_t T = mysteps;
+    uint32_t T = mysteps, Tmin = live ? mysteps : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(T, o); T = v > T ? v : T; }
-    T = sgpr((T + 7) & ~7u);
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t v = __shfl_xor(T, o), v2 = __shfl_xor(Tmin, o);
+        T = v > T ? v : T; Tmin = v2 < Tmin ? v2 : Tmin;
+    }
+    T = sgpr((T + 7) & ~7u); Tmin = sgpr(Tmin);
     const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
     uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t->n, ctx_n + (uint64_t)tile * 9, (int)c)) + 3;
     uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
@@ -205,25 +208,35 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     } else e = tab[sy0 & 255u];
     for (uint32_t kb = 0; kb < T; kb += 8) {
         uint32_t cb = 0;  // words the pair has staged in this block
+        // eight steps; FULL (compile time): every lane of the wave is inside its stream for the whole block, no per-lane activity test
+        auto steps8 = [&](auto fullc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            EncSym en = e;
-            if (BIG) e = E[u];
-            else if (u < 7) en = tab[((u + 1 < 4 ? sy0 : sy1) >> (8 * ((u + 1) & 3))) & 255u];  // entry of the NEXT step, under this step's arithmetic
-            const bool act = kb + (uint32_t)u < mysteps;
-            const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
-            const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
-            const uint32_t other = swap_pair(emit);
-            wb[emit ? cb + (par ? other : 0u) : 16u + par] = (uint32_t)s;  // state0's word first (libxpng.c:370-373)
-            if (emit) s >>= 32;
-            cb += emit + other;
-            if (act) {
-                const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
-                const uint64_t q = __umul64hi(s, rcp) >> rsh;
-                s += e.bias + q * (uint64_t)(cmpl_base - freq);
+            for (int u = 0; u < 8; u++) {
+                EncSym en = e;
+                if (BIG) e = E[u];
+                else if (u < 7) en = tab[((u + 1 < 4 ? sy0 : sy1) >> (8 * ((u + 1) & 3))) & 255u];  // entry of the NEXT step, under this step's arithmetic
+                const bool act = FULL || kb + (uint32_t)u < mysteps;
+                const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
+                const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
+                // the spill handling (pair swap, LDS store, state shift, count) sits behind a wave-uniform branch: the alpha streams
+                // of a wave spill in about a third of the steps (a state spills once in ~160), so most steps are the arithmetic only
+                if (!BIG || __ballot(emit)) {
+                    const uint32_t other = swap_pair(emit);
+                    wb[emit ? cb + (par ? other : 0u) : 16u + par] = (uint32_t)s;  // state0's word first (libxpng.c:370-373)
+                    if (emit) s >>= 32;
+                    cb += emit + other;
+                }
+                if (act) {
+                    const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
+                    const uint64_t q = __umul64hi(s, rcp) >> rsh;
+                    s += e.bias + q * (uint64_t)(cmpl_base - freq);
+                }
+                if (!BIG) e = en;
             }
-            if (!BIG) e = en;
-        }
+        };
+        if (kb + 8 <= Tmin) steps8(std::true_type{});
+        else steps8(std::false_type{});
         // ---- boundary: the next block's symbols land FIRST (the wait in front of it then covers the load issued a block ago
         // and nothing younger: behind this block's stores it would also wait for their acknowledgement), then the staged
         // words go out (lane `par` stores words 8 par .. 8 par + 7) and the block after next is requested
