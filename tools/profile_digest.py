@@ -17,7 +17,9 @@ kern = [{"kernel": k, "workgroups": g, "launches": len(v), "total_ms": round(sum
 # the roofline measurement = the longest run of consecutive chooser / transform launches on the batched grid with no other
 # kernel of the library in between (the pipelined steps interleave other kernels)
 xp = [r for r in rows if "xpng" in r["Kernel_Name"]]
-def is_roof(r): return name(r).startswith(("k_chooser", "k_m1_transform"))
+# (the headline leg's pair: RGBA unless the trace holds none)
+pair = ("k_chooser<4>", "k_m1_transform_rgba") if any(name(r).startswith("k_m1_transform_rgba") for r in xp) else ("k_chooser", "k_m1_transform")
+def is_roof(r): return name(r).startswith(pair)
 best, cur = [], []
 for r in xp:
     if is_roof(r): cur.append(r)
@@ -26,7 +28,7 @@ for r in xp:
         cur = []
 if len(cur) > len(best): best = cur
 roof = {}
-for key in ("k_chooser", "k_m1_transform"):
+for key in pair:
     iso = [dur(r) for r in best if name(r).startswith(key)]
     if not iso: continue
     k, g = next((name(r), wg(r)) for r in best if name(r).startswith(key))
