@@ -274,9 +274,22 @@ static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blob_in, c->cap_blob_in, blobs_len)) return 1;
     HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream));
     if (xpnghip_decode_device(c, mode, c->d_blob_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr)) return 1;
+    // While the kernels run: touch the caller's (typically freshly malloc()ed) raster, one write per page, on a few threads.  Its
+    // first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.
+    if (s >= (32u << 20) && !getenv("XPNG_NO_PREFAULT")) {
+        constexpr int NT = 4;
+        std::thread th[NT];
+        const uint64_t part = ((s / NT) + 4095) & ~4095ull;
+        for (int t = 0; t < NT; t++) {
+            const uint64_t a = std::min<uint64_t>(s, t * part), b = std::min<uint64_t>(s, (t + 1) * part);
+            th[t] = std::thread([=] { for (uint64_t o = a; o < b; o += 4096) raster[o] = 0; });
+        }
+        for (int t = 0; t < NT; t++) th[t].join();
+    }
     const int st = xpnghip_ctx_decode_status(c, nullptr);
     if (st == 1) return fail("corrupt file: a tile header is inconsistent with the tile table");
     if (st != 0) return fail("decode failed");
+    // (a pinned staging buffer with chunked copies and host copy threads measured no better than this plain copy: 21.8 against 21.5 ms)
     HIPCHK(hipMemcpy(raster, c->d_raster, s, hipMemcpyDeviceToHost));
     return 0;
 }
