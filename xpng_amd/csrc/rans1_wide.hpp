@@ -11,6 +11,7 @@
 //   k_rans1_finish  wave per (tile, slot): states, block type, the frequency-table "piece" for the shared bit stream b
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 #include "m2_encode.hpp"
 #include "rans2.hpp"
 
@@ -100,10 +101,13 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     // chunk c = pairs 8c .. 8c+7 (16 bytes); a lane walks its chunks from the top one down to 0, and all lanes of the wave reach
     // chunk 0 together: wave chunk counter C runs Cmax-1 .. 0 and a lane is inside its stream when C < nchunks
     const uint32_t nchunks = (pairs + 7) >> 3;
-    uint32_t Cmax = nchunks;
+    uint32_t Cmax = nchunks, Cfull = live ? pairs >> 3 : 0u;  // chunks below Cfull are complete (8 pairs) for this lane
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(Cmax, o); Cmax = v > Cmax ? v : Cmax; }
-    Cmax = sgpr(Cmax);
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t v = __shfl_xor(Cmax, o), v2 = __shfl_xor(Cfull, o);
+        Cmax = v > Cmax ? v : Cmax; Cfull = v2 < Cfull ? v2 : Cfull;
+    }
+    Cmax = sgpr(Cmax); Cfull = sgpr(Cfull);
     const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
     uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t->n, slot));
     uint32_t *w = out + 4;
@@ -137,18 +141,28 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     for (uint32_t C = Cmax; C > 0;) {
         C--;
         uint32_t cb = 0;  // words the pair has staged in this chunk
+        // the chunk's eight table entries are read up front, back to back (inside the steps each 16-byte LDS read sat in front of
+        // the spill test that needs its frequency: one LDS latency per step instead of one per chunk)
+        EncSym E[8];
 #pragma unroll
-        for (int u = 7; u >= 0; u--) {
-            const EncSym e = tab[((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u];
-            const bool act = 8 * C + (uint32_t)u < pairs;
-            const uint32_t freq = e.freq_shift & 0xFFFF;
-            const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
-            const uint32_t other = swap_pair(emit);
-            wb[emit ? cb + (par ? 0u : other) : 16u + par] = (uint32_t)s;  // state1's word first (libxpng.c:229-236)
-            if (emit) s >>= 32;
-            cb += emit + other;
-            if (act) put(e);
-        }
+        for (int u = 0; u < 8; u++) E[u] = tab[((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u];
+        auto steps8 = [&](auto fullc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(fullc)::value;  // every lane of the wave has all 8 pairs of this chunk: no activity test
+#pragma unroll
+            for (int u = 7; u >= 0; u--) {
+                const EncSym e = E[u];
+                const bool act = FULL || 8 * C + (uint32_t)u < pairs;
+                const uint32_t freq = e.freq_shift & 0xFFFF;
+                const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
+                const uint32_t other = swap_pair(emit);
+                wb[emit ? cb + (par ? 0u : other) : 16u + par] = (uint32_t)s;  // state1's word first (libxpng.c:229-236)
+                if (emit) s >>= 32;
+                cb += emit + other;
+                if (act) put(e);
+            }
+        };
+        if (C < Cfull) steps8(std::true_type{});
+        else steps8(std::false_type{});
         // ---- boundary: next chunk's symbols land, then the staged words go out (lane `par` stores words 8 par .. 8 par + 7)
         land();
         asm volatile("" : "+v"(sy0), "+v"(sy1) : : "memory");
