@@ -94,8 +94,10 @@ def test_stage_planes_and_streams_match_oracle(gpu, po, kind, w, h, alpha):
     ctx = gpu.Context(w, h, ch)
     d_r = torch.from_numpy(raster).cuda()
     d_b = torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
-    ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
     assert ctx.tiles() == po.tile_table(w, h, ch)
+    # BASELINE config-2 entry point: chooser + transform, the five symbol planes left in HBM
+    ctx.transform_device(d_r.data_ptr())
+    all_planes = []
     for ti, t in enumerate(ctx.tiles()):
         pr, sums = po.choose_predictor(raster, t)
         assert ctx.fetch("sums", ti).view(np.uint32).tolist() == sums
@@ -103,6 +105,14 @@ def test_stage_planes_and_streams_match_oracle(gpu, po, kind, w, h, alpha):
         planes = po.m1_planes(raster, t, pr)
         for k in ("nl", "r", "g", "b") + (("a",) if ch == 4 else ()):
             assert np.array_equal(ctx.fetch(k, ti), planes[k]), (ti, k)
+        all_planes.append((pr, planes))
+    # product path: transform and routing fused (no nl / r / g / b planes), then the rANS blocks
+    ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
+    for ti, t in enumerate(ctx.tiles()):
+        pr, planes = all_planes[ti]
+        assert int(ctx.fetch("pr", ti)[0]) == pr
+        if ch == 4:
+            assert np.array_equal(ctx.fetch("a", ti)[1:], planes["a"][1:]), ti   # the alpha symbol plane of the fused kernel
         st = po.m1_streams(raster, t, planes)
         for c in range(9):
             assert np.array_equal(ctx.fetch(10 + c, ti), st["ctx"][c]), (ti, c)

@@ -90,7 +90,9 @@ struct xpnghip_ctx {
     std::vector<TileDesc> tiles;  // the N tiles of ONE image (host copy); the device table has B * N entries
     uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
     TileDesc *d_tiles = nullptr;
-    uint8_t *d_planes = nullptr, *d_scratch = nullptr;
+    uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (5 symbol planes): allocated on first use (config-2 entry, mode 2, XPNG_UNFUSED)
+    uint8_t *d_aplane = nullptr;        // alpha symbol plane of the fused product path (always there)
+    const uint8_t *alpha_src = nullptr; // where the last encode left its alpha symbols (debug_fetch 5)
     uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
     uint64_t *d_off = nullptr, *d_totals = nullptr, *d_dbg = nullptr;
     uint64_t *d_blob_len = nullptr;       // decode: B blob lengths
@@ -138,7 +140,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
+    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_aplane, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_blob_in, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
                     c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -187,7 +189,7 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         c->ws_bytes += (bytes);                                                                    \
     } while (0)
     ALLOC(c->d_tiles, VN * sizeof(TileDesc));
-    ALLOC(c->d_planes, 5 * c->plane_stride + 8192);   // + slack: LDS-ring staging reads whole 1 KB units
+    ALLOC(c->d_aplane, c->plane_stride + 8192);       // + slack: LDS-ring staging reads whole 1 KB units
     ALLOC(c->d_scratch, c->scratch_img * batch + 8192);
     c->dec.arena = c->d_scratch;   // decode keeps its symbol / residual planes in the encode stream scratch (DecodeWs::arena)
     c->dec.arena_bytes = c->scratch_img * batch + 8192;
@@ -281,9 +283,31 @@ static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1)
     return (t0 == c->r0 && t1 == c->r1 && !getenv("XPNG_IMAGE_MAJOR")) ? c->d_order : nullptr;
 }
 
+// the five symbol planes of the unfused form (BASELINE config-2 entry, mode 2, XPNG_UNFUSED): 5 B/px, allocated on first use
+static int ensure_planes(xpnghip_ctx *c) {
+    if (c->d_planes) return 0;
+    HIPCHK(hipMalloc((void **)&c->d_planes, 5 * c->plane_stride + 8192));
+    c->ws_bytes += 5 * c->plane_stride + 8192;
+    return 0;
+}
+
+// predictor chooser (pp_rgbx).  Launch only.
+template <int PXSZ>
+static int launch_chooser(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+    const uint32_t cnt = t1 - t0, total = nimg * cnt;
+    const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};
+    const uint64_t bpr = c->W * PXSZ;
+    if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
+    else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
+    const uint32_t strips = 16;
+    k_chooser<PXSZ><<<total * strips, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, strips, c->d_sums);
+    return 0;
+}
+
 // chooser + transform (BASELINE config 2).  Launch only; no sync.  d_in_ptrs already holds the raster pointers.
 template <int PXSZ>
 static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+    if (ensure_planes(c)) return 1;
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     // image-major here: these two kernels stream the rasters, and neighbouring workgroups on neighbouring rows of ONE raster
     // keep HBM pages open (measured with 64 distinct rasters: 2.25 ms per launch against 2.4-2.6 tile-major)
@@ -291,10 +315,7 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
-    if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
-    else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
-    const uint32_t strips = 16;
-    k_chooser<PXSZ><<<total * strips, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, strips, c->d_sums);
+    if (launch_chooser<PXSZ>(c, nimg, t0, t1, s)) return 1;
     uint32_t max_w = 0, max_h = 0;
     for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (PXSZ == 4 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
@@ -334,33 +355,68 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
-    if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
+    uint32_t max_w = 0;
+    for (uint32_t i = t0; i < t1; i++) max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w;
+    // Product path: chooser, then transform and routing FUSED (k_m1_fused: the nl / r / g / b planes never exist; the alpha
+    // symbols go to their own 1 B/px plane).  XPNG_UNFUSED=1 or tiles wider than the LDS-staged form takes: k_m1_transform_* +
+    // k_m1_streams through the five planes.
+    const bool fused = max_w <= TR_MAXW && !getenv("XPNG_UNFUSED");
     const bool narrow = getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"));
-    // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the transform's alpha plane,
-    // so their preparation and the chains themselves start here, on their own stream, beside stream formation.
-    const bool alpha_early = !narrow && PXSZ == 4;
-    if (alpha_early) {
-        if (!c->enc_side) {
-            HIPCHK(hipStreamCreateWithFlags(&c->enc_side, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
-        }
+    const bool small_wg = (uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS");
+    // RGBA, fused: the alpha symbols come from a small pass of their own (they do not depend on the predictor choice), so the
+    // alpha chains start before the chooser has even run; XPNG_ALPHA_IN_FUSED=1: k_m1_fused writes them (one raster read less,
+    // the alpha chains start ~5 ms later: measured 16.0 against 13.7 ms per 64 images at 3 slots)
+    const bool alpha_pass = fused && PXSZ == 4 && !getenv("XPNG_ALPHA_IN_FUSED");
+    if (!fused && ensure_planes(c)) return 1;  // (before their address is taken below)
+    const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
+    const bool alpha_side = !narrow && PXSZ == 4;
+    if (alpha_side && !c->enc_side) {
+        HIPCHK(hipStreamCreateWithFlags(&c->enc_side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
+    }
+    auto alpha_branch = [&](hipStream_t as) -> int {  // alpha plane -> tables -> chains, on the side stream
+        k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
+        k_rans2_chain2<true><<<(total + 31) / 32, 64, 0, as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        HIPCHK(hipEventRecord(c->ev_enc_join, as));
+        return 0;
+    };
+    if (alpha_pass) {
+        uint32_t max_n = 0;
+        for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
+        const uint32_t bpt = (max_n + 1024 * TG_REPS - 1) / (1024 * TG_REPS);
+        const TileSel isel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};  // image-major: a streaming pass over the rasters
+        hipStream_t as = alpha_side ? c->enc_side : s;
+        if (alpha_side) { HIPCHK(hipEventRecord(c->ev_enc_fork, s)); HIPCHK(hipStreamWaitEvent(as, c->ev_enc_fork, 0)); }
+        k_alpha_syms<<<total * bpt, 256, 0, as>>>(c->d_in_ptrs, bpr, c->d_tiles, isel, bpt, c->d_aplane);
+        if (alpha_side && alpha_branch(as)) return 1;
+    }
+    if (fused) {
+        if (launch_chooser<PXSZ>(c, nimg, t0, t1, s)) return 1;
+        if (small_wg) k_m1_fused<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * PXSZ, c->d_tiles, sel, c->d_sums, alpha_pass ? nullptr : c->d_aplane, c->d_scratch, c->d_ctx_n, c->d_k_n);
+        else k_m1_fused<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * PXSZ, c->d_tiles, sel, c->d_sums, alpha_pass ? nullptr : c->d_aplane, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    } else if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
+    c->alpha_src = planesA + 4 * c->plane_stride;
+    // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
+    // preparation and the chains themselves run on their own stream (started above when the alpha pass made the plane; here, behind
+    // the kernel that wrote it, otherwise)
+    if (alpha_side && !alpha_pass) {
         HIPCHK(hipEventRecord(c->ev_enc_fork, s));
         HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
-        k_rans2_prep<<<total, 64, 0, c->enc_side>>>(c->d_tiles, sel, 9, 1, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        k_rans2_chain2<true><<<(total + 31) / 32, 64, 0, c->enc_side>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
-        HIPCHK(hipEventRecord(c->ev_enc_join, c->enc_side));
+        if (alpha_branch(c->enc_side)) return 1;
     }
-    if ((uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    if (!fused) {
+        if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+        else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    }
     if (narrow) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
-        k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
+        k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
-        if (alpha_early) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
-        k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
+        k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
+        k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
+        k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
     k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
@@ -512,7 +568,10 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
         if (cap < 1) return -1;
         *(uint8_t *)out = pr;
         return 1;
+    } else if (what == 5 && c->alpha_src) {
+        src = c->alpha_src + t.pbase; bytes = t.n;
     } else if (what >= 1 && what <= 5) {
+        if (!c->d_planes) return -1;  // the five planes exist after xpnghip_m1_transform_device (config-2 entry) or a mode-2 encode
         src = c->d_planes + (uint64_t)(what - 1) * c->plane_stride + t.pbase; bytes = t.n;
     } else if (what >= 10 && what <= 18) {
         if (!d2h(tmp, c->d_ctx_n + tile * 9, 36)) return -1;
