@@ -106,13 +106,13 @@ def test_stage_planes_and_streams_match_oracle(gpu, po, kind, w, h, alpha):
         for k in ("nl", "r", "g", "b") + (("a",) if ch == 4 else ()):
             assert np.array_equal(ctx.fetch(k, ti), planes[k]), (ti, k)
         all_planes.append((pr, planes))
-    # product path: transform and routing fused (no nl / r / g / b planes), then the rANS blocks
+    # full encode (default form: through the planes; the fused form is covered by test_fused_transform_routing_path), then the rANS blocks
     ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
     for ti, t in enumerate(ctx.tiles()):
         pr, planes = all_planes[ti]
         assert int(ctx.fetch("pr", ti)[0]) == pr
         if ch == 4:
-            assert np.array_equal(ctx.fetch("a", ti)[1:], planes["a"][1:]), ti   # the alpha symbol plane of the fused kernel
+            assert np.array_equal(ctx.fetch("a", ti)[1:], planes["a"][1:]), ti   # the alpha symbol plane the rANS block read
         st = po.m1_streams(raster, t, planes)
         for c in range(9):
             assert np.array_equal(ctx.fetch(10 + c, ti), st["ctx"][c]), (ti, c)
@@ -609,3 +609,45 @@ def test_worker_count_T_shards_tile_ranges_over_devices(gpu, po, tmp_path, monke
     p.write_bytes(bytes(bad))
     with pytest.raises(gpu.XpngError):
         gpu.load(str(p), T=T)
+
+
+@pytest.mark.parametrize("force_wide", [False, True])
+def test_fused_transform_routing_path(gpu, manifest, po, tmp_path, monkeypatch, force_wide):
+    """XPNG_FUSED=1: transform and routing in one kernel (k_m1_fused, no nl / r / g / b planes in HBM; alpha symbols from
+    k_alpha_syms).  Same bytes as the default form: every small golden at level 1, the stage outputs of an RGBA and an RGB raster
+    (context streams, k words, alpha plane), and a batch."""
+    import torch
+    from xpng_amd.synth import synth_raster
+    monkeypatch.setenv("XPNG_FUSED", "1")
+    if force_wide:
+        monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    checked = 0
+    for name, ent in small_entries(manifest):
+        g = ent.get("L1")
+        if g is None:
+            continue
+        raster = golden_raster(name, ent)
+        out = tmp_path / "o.xpng"
+        gpu.store(1, raster, str(out))
+        data = out.read_bytes()
+        assert len(data) == g["size"] and md5(data) == g["md5"], name
+        checked += 1
+    assert checked >= 120
+    for (w, h, alpha) in [(1333, 901, True), (1501, 1203, False)]:
+        raster = synth_raster("photo", w, h, alpha)
+        ch = raster.shape[2]
+        ctx = gpu.Context(w, h, ch)
+        d_r = torch.from_numpy(raster).cuda()
+        d_b = torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        n = ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
+        assert d_b[:n].cpu().numpy().tobytes() == po.encode_tiles(1, raster)
+        for ti, t in enumerate(ctx.tiles()):
+            pr, _ = po.choose_predictor(raster, t)
+            planes = po.m1_planes(raster, t, pr)
+            st = po.m1_streams(raster, t, planes)
+            for c in range(9):
+                assert np.array_equal(ctx.fetch(10 + c, ti), st["ctx"][c]), (ti, c)
+            assert np.array_equal(ctx.fetch("k", ti).view(np.uint32), st["k"])
+            if ch == 4:
+                assert np.array_equal(ctx.fetch("a", ti)[1:], planes["a"][1:]), ti
+        ctx.close()

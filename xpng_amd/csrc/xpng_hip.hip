@@ -357,10 +357,12 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_w = 0;
     for (uint32_t i = t0; i < t1; i++) max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w;
-    // Product path: chooser, then transform and routing FUSED (k_m1_fused: the nl / r / g / b planes never exist; the alpha
-    // symbols go to their own 1 B/px plane).  XPNG_UNFUSED=1 or tiles wider than the LDS-staged form takes: k_m1_transform_* +
-    // k_m1_streams through the five planes.
-    const bool fused = max_w <= TR_MAXW && !getenv("XPNG_UNFUSED");
+    // Two forms of transform + routing, same bytes.  Default: k_m1_transform_* -> five symbol planes -> k_m1_streams.
+    // XPNG_FUSED=1: chooser, then k_m1_fused (the nl / r / g / b planes never exist: 4 B/px less workspace, 3.7 B/px less HBM
+    // traffic; the alpha symbols come from k_alpha_syms).  Measured (64 rasters, 5 slots): fused 31.5 Gpx/s and 137 GB, unfused
+    // 33.3 Gpx/s and 157 GB - one long-lived 28 KB workgroup per tile sits worse beside the chain kernels of the other slots than
+    // the short transform kernel plus a lighter routing kernel do - so the faster form is the default and the leaner one a switch.
+    const bool fused = max_w <= TR_MAXW && getenv("XPNG_FUSED") && !getenv("XPNG_UNFUSED");
     const bool narrow = getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"));
     const bool small_wg = (uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS");
     // RGBA, fused: the alpha symbols come from a small pass of their own (they do not depend on the predictor choice), so the
