@@ -1217,6 +1217,16 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
 // 16-bit-lane gradient, byte-parallel add); residual words arrive as one 16-byte load per lane every 4 steps and pixels
 // leave as one 16-byte store (single dwords at the two ends of a row).  RGBA only.
 constexpr uint32_t RB_MAXW = 2048;  // seam buffer, pixels
+// Row staging through LDS.  A lane's row moves between HBM and the wave in whole, 64-byte-aligned 16-word chunks - four
+// back-to-back 16-byte requests per lane for ONE chunk of its own row, once per 16 steps - instead of one 16-byte piece every
+// 4 steps: with thousands of waves x 64 rows in flight the pieces of a line used to arrive microseconds apart, L2 had dropped the
+// line in between, and the kernel moved 2.2-2.4x its algorithmic bytes (profiles/r02_pmc_step_mem.json: 21.9 B/px against 8).
+// Each lane owns a two-chunk ring per direction (the lane skew makes the word a lane needs at a step lane-dependent, which LDS
+// addressing absorbs): residual words [0,32) + a 4-word mirror of words 0-3, so that a lane's unaligned 4-word read never
+// wraps; pixels [0,32) + a 4-word spill zone behind them for the 4-word write that straddles the ring's end.
+constexpr uint32_t RB_RING = 36;                       // words per lane and direction (a stride of 9 x 16 bytes: conflict-free b128)
+constexpr uint32_t RB_STAGE_WORDS = 64 * RB_RING * 2;  // LDS words in front of the seam row
+constexpr size_t RB_LDS_BYTES(uint32_t max_w) { return (size_t)RB_STAGE_WORDS * 4 + (size_t)max_w * 4 + 256; }
 __device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-byte a + b (mod 256)
     return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
 }
@@ -1224,32 +1234,53 @@ __device__ __forceinline__ uint32_t swar_add8(uint32_t a, uint32_t b) {  // per-
 // predicts from the left and column 0 from above.  Modes 2 and 3 occur in gray tiles of mode 2 only (libxpng.c:890-895).
 template <int PXSZ>
 __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__restrict__ dst, uint64_t bpr, const uint32_t *__restrict__ rs,
-                                                uint32_t first, int predmode, uint32_t *seam, uint32_t dbgflags) {
+                                                uint32_t first, int predmode, uint32_t *stage, uint32_t *seam, uint32_t dbgflags) {
     const uint32_t lane = threadIdx.x & 63;
     const bool grad = predmode == 1;
     const int32_t w = (int32_t)t.w;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x4_a4r __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t *rin = stage + lane * RB_RING, *rout = stage + 64 * RB_RING + lane * RB_RING;
     for (uint32_t yb = 0; yb < t.h; yb += 64) {
         const uint32_t y = yb + lane;
         const bool active = y < t.h;
-        // (a lane reads up to 63 words before and ~100 after its row: inside the tile's words, or the >= 192 words of slack behind them; never used)
-        const uint32_t *rsrow = rs + (active ? (uint64_t)y * t.w : (uint64_t)lane);
+        // (a lane without a row reads the tile's last row again and stores nothing)
+        const uint32_t *rsrow = rs + (uint64_t)(active ? y : t.h - 1) * t.w;
         uint8_t *drow = dst + (uint64_t)(active ? y : 0) * bpr;
+        // positions: p = x + a counts words from the 64-byte boundary in front of the row's first residual word (chunk c = words
+        // [16c, 16c+16), chunks 0..Lc hold the row; at most 15 words in front of / behind the row are read: the neighbouring rows
+        // of the tile, or the slack around the residual plane); po = x + ao the same for the pixels of the raster row
+        const int32_t a = (int32_t)(((uintptr_t)rsrow >> 2) & 15u);
+        const u32x4 *rsal = reinterpret_cast<const u32x4 *>(rsrow - a);
+        const int32_t Lc = (a + w - 1) >> 4;
+        const int32_t ao = PXSZ == 4 ? (int32_t)(((uintptr_t)drow >> 2) & 15u) : 0;
+        uint8_t *dal = drow - 4 * ao;
+        const int32_t olo = active ? ao : 0, ohi = active ? ao + w : 0;  // valid pixel positions of this lane
+        const uint32_t pho = (uint32_t)(ao - (int32_t)lane) & 3u;      // every 4-word pixel write of this lane starts at po = pho (mod 4)
         const uint32_t S = t.w + 63;
         uint32_t prev = 0, U = 0, ev = 0;
-        // residual words are read four groups (16 steps) ahead: loads and stores retire in issue order on this ISA, so the
-        // distance is also what a store gets to complete before the wave next waits on a load
-        u32x4_a4r ring[4];
+#define XPNG_RB_CLAMP(c) ((c) < 0 ? 0 : (c) > Lc ? Lc : (c))
+#define XPNG_RB_LOAD(G, c) { const u32x4 *cp_ = rsal + 4 * XPNG_RB_CLAMP(c); G[0] = cp_[0]; G[1] = cp_[1]; G[2] = cp_[2]; G[3] = cp_[3]; }
+#define XPNG_RB_PUT(G, c) { const uint32_t sl_ = (uint32_t)XPNG_RB_CLAMP(c) & 1u; u32x4 *rp_ = reinterpret_cast<u32x4 *>(rin + 16 * sl_); \
+                            rp_[0] = G[0]; rp_[1] = G[1]; rp_[2] = G[2]; rp_[3] = G[3]; if (sl_ == 0) *reinterpret_cast<u32x4 *>(rin + 32) = G[0]; }
+        int32_t p0 = a - (int32_t)lane, po0 = ao - (int32_t)lane;  // positions of this lane at the first step of the block
+        u32x4 G[4];
+        XPNG_RB_LOAD(G, p0 >> 4);
+        XPNG_RB_PUT(G, p0 >> 4);
+        XPNG_RB_LOAD(G, (p0 >> 4) + 1);
+        for (uint32_t s0 = 0; s0 < S; s0 += 16, p0 += 16, po0 += 16) {
+            // block of 16 steps: the chunk requested a block ago lands in the ring, the next one is requested, and the block's 16
+            // residual words come out of the ring (they lie in chunks p0 >> 4 and (p0 >> 4) + 1)
+            XPNG_RB_PUT(G, (p0 >> 4) + 1);
+            XPNG_RB_LOAD(G, (p0 >> 4) + 2);
+            u32x4 cur[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) ring[q] = *reinterpret_cast<const u32x4_a4r *>(rsrow + (4 * q - (int32_t)lane));
-        for (uint32_t s0 = 0; s0 < S; s0 += 16) {
+            for (int q = 0; q < 4; q++) cur[q] = *reinterpret_cast<const u32x4_a4r *>(rin + ((uint32_t)(p0 + 4 * q) & 31u));
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const uint32_t s = s0 + 4 * q;
-            const u32x4_a4r cur4 = ring[q];
-            ring[q] = *reinterpret_cast<const u32x4_a4r *>(rsrow + ((int32_t)s + 16 - (int32_t)lane));
             if (yb > 0 && (s & 63u) == 0 && (int32_t)s < w) ev = (int32_t)(s + lane) < w ? seam[s + lane] : 0u;  // next 64 columns of the row above the band
-            const uint32_t rwv[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+            const uint32_t rwv[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
             uint32_t o[4];
             const int32_t x0 = (int32_t)s - (int32_t)lane;
 #pragma unroll
@@ -1282,30 +1313,55 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
                 if (lane == 63 && on) seam[x] = px;  // (a full band: lane 63 is an existing row)
             }
             if (PXSZ == 4) {
-                if (dbgflags & 1) { if (lane == 0 && x0 >= 0 && x0 + 3 < w) *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]}; }
-                else if (active && x0 >= 0 && x0 + 3 < w) {
-                    *reinterpret_cast<u32x4_a4r *>(drow + 4ll * x0) = u32x4_a4r{o[0], o[1], o[2], o[3]};
-                } else if (active) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { const int32_t x = x0 + k; if (x >= 0 && x < w) *reinterpret_cast<uint32_t *>(drow + 4ll * x) = o[k]; }
-                }
+                // four pixels into the lane's ring (words past 31: the spill zone, taken back when chunk 0 of the ring is flushed)
+                *reinterpret_cast<u32x4_a4r *>(rout + ((uint32_t)(po0 + 4 * q) & 31u)) = u32x4_a4r{o[0], o[1], o[2], o[3]};
             } else {
                 // RGB: the (marker) top byte of a pixel word is dropped; four pixels are 12 consecutive bytes at any alignment
                 typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
-                const uint32_t p0 = o[0] & 0xFFFFFFu, p1 = o[1] & 0xFFFFFFu, p2 = o[2] & 0xFFFFFFu, p3 = o[3] & 0xFFFFFFu;
+                const uint32_t q0 = o[0] & 0xFFFFFFu, q1 = o[1] & 0xFFFFFFu, q2 = o[2] & 0xFFFFFFu, q3 = o[3] & 0xFFFFFFu;
                 if (active && x0 >= 0 && x0 + 3 < w) {
-                    *reinterpret_cast<u32x3_a1 *>(drow + 3ll * x0) = u32x3_a1{p0 | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+                    *reinterpret_cast<u32x3_a1 *>(drow + 3ll * x0) = u32x3_a1{q0 | (q1 << 24), (q1 >> 8) | (q2 << 16), (q2 >> 16) | (q3 << 8)};
                 } else if (active) {
-                    const uint32_t pk[4] = {p0, p1, p2, p3};
+                    const uint32_t pk[4] = {q0, q1, q2, q3};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int32_t x = x0 + k;
-                        if (x >= 0 && x < w) { uint8_t *q = drow + 3ll * x; q[0] = (uint8_t)pk[k]; q[1] = (uint8_t)(pk[k] >> 8); q[2] = (uint8_t)(pk[k] >> 16); }
+                        if (x >= 0 && x < w) { uint8_t *qd = drow + 3ll * x; qd[0] = (uint8_t)pk[k]; qd[1] = (uint8_t)(pk[k] >> 8); qd[2] = (uint8_t)(pk[k] >> 16); }
                     }
                 }
             }
           }
+            if (PXSZ == 4) {
+                // the pixel chunk this block completed (the one holding the block's first position) leaves as four 16-byte stores
+#define XPNG_RB_FLUSH(fc_)                                                                                                              \
+                {                                                                                                                       \
+                    const int32_t fc = (fc_);                                                                                           \
+                    const u32x4 *fp = reinterpret_cast<const u32x4 *>(rout + 16 * ((uint32_t)fc & 1u));                                 \
+                    u32x4 v[4] = {fp[0], fp[1], fp[2], fp[3]};                                                                          \
+                    if (((uint32_t)fc & 1u) == 0) {                                                                                     \
+                        const u32x4 sp = *reinterpret_cast<const u32x4 *>(rout + 32);                                                   \
+                        v[0].x = pho > 0 ? sp.x : v[0].x; v[0].y = pho > 1 ? sp.y : v[0].y; v[0].z = pho > 2 ? sp.z : v[0].z;           \
+                    }                                                                                                                   \
+                    if (!(dbgflags & 1)) {                                                                                              \
+                        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                 \
+                            const int32_t pq = fc * 16 + 4 * q;                                                                         \
+                            if (pq >= olo && pq + 4 <= ohi) *reinterpret_cast<u32x4 *>(dal + 4ll * pq) = v[q];                          \
+                            else if (pq + 4 > olo && pq < ohi) {                                                                        \
+                                const uint32_t vv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};                                                \
+                                _Pragma("unroll") for (int k = 0; k < 4; k++)                                                           \
+                                    if (pq + k >= olo && pq + k < ohi) *reinterpret_cast<uint32_t *>(dal + 4ll * (pq + k)) = vv[k];     \
+                            }                                                                                                           \
+                        }                                                                                                               \
+                    }                                                                                                                   \
+                }
+                XPNG_RB_FLUSH(po0 >> 4)
+            }
         }
+        if (PXSZ == 4) XPNG_RB_FLUSH(po0 >> 4)  // (po0 was advanced past the last block: its chunk holds the tail of the row, if anything)
+#undef XPNG_RB_FLUSH
+#undef XPNG_RB_CLAMP
+#undef XPNG_RB_LOAD
+#undef XPNG_RB_PUT
     }
 }
 
@@ -1313,7 +1369,8 @@ template <int PXSZ>
 __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                        TileSel sel, const uint32_t *__restrict__ resid,
                                                        uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0) {
-    extern __shared__ uint32_t seam[];  // one row of the widest tile of the launch (bottom row of the band above)
+    extern __shared__ uint32_t rb_lds[];  // the lanes' staging rings, then one row of the widest tile of the launch (bottom row of the band above)
+    uint32_t *seam = rb_lds + RB_STAGE_WORDS;
     const uint32_t j = j0 + blockIdx.x, lane = threadIdx.x & 63;
     const DecTile *d = info + j;
     const uint32_t type = d->type;
@@ -1328,7 +1385,7 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
     }
     const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
     const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | (PXSZ == 4 ? (kw0 & 255u) << 24 : 0u);
-    recon_band_core<PXSZ>(t, dst, bpr, resid + t.pbase, first, (int)((type >> 1) & 1), seam, dbgflags);
+    recon_band_core<PXSZ>(t, dst, bpr, resid + t.pbase, first, (int)((type >> 1) & 1), rb_lds, seam, dbgflags);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1438,7 +1495,8 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
         if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
-        if (wide) k_dec_alpha<256><<<total, 256, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
+        const size_t pad_al = getenv("XPNG_PAD_AL") ? (size_t)atoi(getenv("XPNG_PAD_AL")) : 0;
+        if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
@@ -1467,7 +1525,8 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // 16-byte loads and stores (64 rows per instruction) fill the memory pipeline's queues, and the chain kernels of the other
     // pipeline slots, which touch memory once per 8-step block, then wait for their words: decode-only rate at 3 slots
     // 43 -> 51 Gpx/s, combined bench +4 % (XPNG_RECON_LDS_PAD=0 turns it off)
-    const size_t dbg_pad = getenv("XPNG_RECON_LDS_PAD") ? (size_t)atoi(getenv("XPNG_RECON_LDS_PAD")) : 12288;
+    const size_t dbg_pad = getenv("XPNG_RECON_LDS_PAD") ? (size_t)atoi(getenv("XPNG_RECON_LDS_PAD")) : 0;
+    const size_t pad_rs = getenv("XPNG_PAD_RS") ? (size_t)atoi(getenv("XPNG_PAD_RS")) : 0;
     if (split) {
         if (!ws.side2) {
             if (hipStreamCreateWithFlags(&ws.side2, hipStreamNonBlocking) != hipSuccess ||
@@ -1484,11 +1543,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         else k_dec_walk<<<jb, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
-            k_dec_resid<4, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<4><<<total - jb, 64, (size_t)max_w * 4 + 256 + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
+            k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
+            k_dec_recon_band<4><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
         } else {
             k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<3><<<total - jb, 64, (size_t)max_w * 4 + 256 + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
+            k_dec_recon_band<3><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
     } else if (wide && !getenv("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
@@ -1496,15 +1555,15 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
-        if (wide) k_dec_resid<4, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<4><<<nt, 64, (size_t)max_w * 4 + 256 + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
+        if (band) k_dec_recon_band<4><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
         if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<3><<<nt, 64, (size_t)max_w * 4 + 256 + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0);
+        if (band) k_dec_recon_band<3><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0);
         else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }

@@ -413,7 +413,8 @@ __global__ __launch_bounds__(1024) void k_m2_dec_recon(const M2DecTile *__restri
 // from wave to wave through LDS and progress counters, which is right for one image and 4x slower per tile in a batch.
 __global__ __launch_bounds__(64) void k_m2_dec_recon_band(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                           const uint32_t *__restrict__ resid, uint8_t *const *__restrict__ rasters, uint64_t bpr) {
-    extern __shared__ uint32_t seam[];
+    extern __shared__ uint32_t rb_lds[];  // staging rings, then the seam row (recon_band_core)
+    uint32_t *seam = rb_lds + RB_STAGE_WORDS;
     const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
     const M2DecTile *d = info + j;
     const uint32_t kind = d->kind;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64) void k_m2_dec_recon_band(const M2DecTile *__res
         first = ((w0 >> 24) & 255u) | (((w0 >> 16) & 255u) << 8) | (((w0 >> 8) & 255u) << 16);
         predmode = (int)((d->m >> 1) & 1);
     }
-    recon_band_core<3>(t, dst, bpr, resid + t.pbase, first, predmode, seam, 0u);
+    recon_band_core<3>(t, dst, bpr, resid + t.pbase, first, predmode, rb_lds, seam, 0u);
 }
 
 inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t total, const M2DecTile *d_info2, const TileDesc *d_tiles,
@@ -469,7 +470,7 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
     const bool wide_recon = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * M2_STREAMS > 2048 || getenv("XPNG_WIDE_RANS")) && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON");
-    if (wide_recon) k_m2_dec_recon_band<<<total, 64, (size_t)max_w * 4 + 256, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr);
+    if (wide_recon) k_m2_dec_recon_band<<<total, 64, RB_LDS_BYTES(max_w), s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr);
     else k_m2_dec_recon<<<total, rthreads, rlds, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, free_ew);
     if (hipGetLastError() != hipSuccess) { err = "mode-2 decode kernel launch failed"; return 1; }
     return 0;

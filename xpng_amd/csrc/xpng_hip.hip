@@ -292,21 +292,23 @@ static int ensure_planes(xpnghip_ctx *c) {
 }
 
 // predictor chooser (pp_rgbx).  Launch only.
+// Occupancy throttles of the bandwidth kernels in the pipelined paths (bytes of unused dynamic LDS per workgroup)
+static size_t env_pad(const char *name) { const char *v = getenv(name); return v ? (size_t)atoi(v) : 0; }
 template <int PXSZ>
-static int launch_chooser(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+static int launch_chooser(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s, size_t pad = 0) {
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};
     const uint64_t bpr = c->W * PXSZ;
     if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
     else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
     const uint32_t strips = 16;
-    k_chooser<PXSZ><<<total * strips, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, strips, c->d_sums);
+    k_chooser<PXSZ><<<total * strips, 256, pad, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, strips, c->d_sums);
     return 0;
 }
 
 // chooser + transform (BASELINE config 2).  Launch only; no sync.  d_in_ptrs already holds the raster pointers.
 template <int PXSZ>
-static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s, size_t pad = 0) {
     if (ensure_planes(c)) return 1;
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     // image-major here: these two kernels stream the rasters, and neighbouring workgroups on neighbouring rows of ONE raster
@@ -315,15 +317,15 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
-    if (launch_chooser<PXSZ>(c, nimg, t0, t1, s)) return 1;
+    if (launch_chooser<PXSZ>(c, nimg, t0, t1, s, pad)) return 1;
     uint32_t max_w = 0, max_h = 0;
     for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (PXSZ == 4 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
+        k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
     } else if (PXSZ == 3 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
+        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
     } else {
         const uint32_t bpt = (max_n + 1024 * TG_REPS - 1) / (1024 * TG_REPS);
         k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride);
@@ -369,6 +371,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     // alpha chains start before the chooser has even run; XPNG_ALPHA_IN_FUSED=1: k_m1_fused writes them (one raster read less,
     // the alpha chains start ~5 ms later: measured 16.0 against 13.7 ms per 64 images at 3 slots)
     const bool alpha_pass = fused && PXSZ == 4 && !getenv("XPNG_ALPHA_IN_FUSED");
+    static const size_t pad_tr = env_pad("XPNG_PAD_TR"), pad_st = env_pad("XPNG_PAD_ST"), pad_ga = env_pad("XPNG_PAD_GA");
     if (!fused && ensure_planes(c)) return 1;  // (before their address is taken below)
     const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
     const bool alpha_side = !narrow && PXSZ == 4;
@@ -397,7 +400,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         if (launch_chooser<PXSZ>(c, nimg, t0, t1, s)) return 1;
         if (small_wg) k_m1_fused<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * PXSZ, c->d_tiles, sel, c->d_sums, alpha_pass ? nullptr : c->d_aplane, c->d_scratch, c->d_ctx_n, c->d_k_n);
         else k_m1_fused<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * PXSZ, c->d_tiles, sel, c->d_sums, alpha_pass ? nullptr : c->d_aplane, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    } else if (launch_transform<PXSZ>(c, nimg, t0, t1, s)) return 1;
+    } else if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr)) return 1;
     c->alpha_src = planesA + 4 * c->plane_stride;
     // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
     // preparation and the chains themselves run on their own stream (started above when the alpha pass made the plane; here, behind
@@ -408,7 +411,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         if (alpha_branch(c->enc_side)) return 1;
     }
     if (!fused) {
-        if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+        if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
         else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     }
     if (narrow) {
@@ -422,7 +425,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
     k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
-    k_tile_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_ctx_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
+    k_tile_gather<<<total, 256, pad_ga, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_ctx_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
     return 0;
