@@ -651,3 +651,47 @@ def test_fused_transform_routing_path(gpu, manifest, po, tmp_path, monkeypatch, 
             if ch == 4:
                 assert np.array_equal(ctx.fetch("a", ti)[1:], planes["a"][1:]), ti
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pb", [13, 15])
+def test_context_stream_with_more_probability_bits_on_the_wide_path(gpu, po, monkeypatch, pb):
+    """The reference writes its nl-context streams with 12 probability bits; the format allows 10..15 (libxpng.c:429-493 reads
+    the width from the block header).  A file whose context blocks were re-coded with 13 / 15 bits by the oracle's encoder must
+    decode to the same raster: on the wide path those streams do not fit the small table layout and go to k_rans2_decode_rest."""
+    monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    from xpng_amd import api
+    from xpng_amd.synth import synth_raster
+    W, H = 1000, 300
+    raster = synth_raster("photo", W, H, False, seed=11).copy()
+    blobs = po.encode_tiles(1, raster)
+    tiles = po.tile_table(W, H, 3)
+    out, o, recoded = bytearray(), 0, 0
+    for ti in range(len(tiles)):
+        L = int.from_bytes(blobs[o:o + 3], "little")
+        tile = bytearray(blobs[o:o + L])
+        o += L
+        if tile[3] == 0:                     # raw tile
+            out += tile
+            continue
+        ksz = int.from_bytes(tile[4:8], "little")
+        q, parts = 4 + ksz, [bytes(tile[:4 + ksz])]
+        for c in range(9):
+            b0 = int.from_bytes(tile[q:q + 4], "little")
+            ty, sz = b0 >> 24, (4 if (b0 >> 24) == 0 else b0 & 0xFFFFFF)
+            blk = bytes(tile[q:q + sz])
+            q += sz
+            if ty >= 3 and c % 2 == ti % 2:  # every other rANS-coded context block of the tile
+                n = int.from_bytes(blk[4:7], "little")
+                syms, _ = po.rans2_decode(blk, n)
+                new = po.rans2_encode(np.bincount(syms, minlength=9).astype(np.uint32), 9, syms, pb)
+                if new[3] >= 3 and new[11] == pb:
+                    blk, recoded = new, recoded + 1
+            parts.append(blk)
+        assert q == L
+        body = b"".join(parts)
+        out += len(body).to_bytes(3, "little") + bytes([tile[3]]) + body[4:]
+    assert recoded >= 4
+    out = bytes(out)
+    assert np.array_equal(po.decode_tiles(1, out, W, H, 3), raster)        # the crafted file is a valid one
+    assert np.array_equal(api.decode_tiles(1, out, W, H, 3), raster)

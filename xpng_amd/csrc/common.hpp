@@ -3,8 +3,25 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace xpng {
+
+// Knock-out switch for timing studies (tools/knockout.py): XPNG_SKIP=name,name,... leaves the named kernels of the batched
+// level-1 paths unlaunched once XPNG_SKIP_AFTER launch sequences have run complete (the workspaces then still hold the
+// previous, identical results, so everything downstream keeps working on valid data).  Never set in production.
+inline uint64_t &dbg_sequences() { static uint64_t n = 0; return n; }
+inline bool dbg_skip(const char *name) {
+    static const char *list = getenv("XPNG_SKIP");
+    if (!list) return false;
+    static const uint64_t after = getenv("XPNG_SKIP_AFTER") ? strtoull(getenv("XPNG_SKIP_AFTER"), nullptr, 10) : 16;
+    if (dbg_sequences() <= after) return false;
+    const size_t n = strlen(name);
+    for (const char *p = list; (p = strstr(p, name)); p += n)
+        if ((p == list || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+    return false;
+}
 
 constexpr uint32_t TILE_AREA = 444u * 444u;  // reference libxpng.c:49
 constexpr uint32_t NL_NONE = 0xFFu;          // nl-plane marker: pixel emits no colour symbol

@@ -179,12 +179,11 @@ namespace xpng {
 //   * decoded symbols go to an LDS ring and are flushed 512 at a time.
 // MAXPB bounds the slot table (2^MAXPB bytes of LDS): 12 for the nl-context streams, 15 for alpha.  A block whose
 // header asks for more than MAXPB is left to the general (MAXPB = 15) launch (`only_over` selects those).
+// One rANS v2 block, one wavefront (the body of k_rans2_decode and of k_rans2_decode_rest below).
 template <int MAXPB>
-__global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__ info,
-                                                     const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first,
-                                                     uint32_t c_count, int only_over, uint8_t *__restrict__ ctxsym,
-                                                     uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg,
-                                                     const WDec *__restrict__ wdec = nullptr) {
+__device__ __forceinline__ void rans2_decode_stream(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                    const uint32_t j, const uint32_t c, int only_over, uint8_t *__restrict__ ctxsym,
+                                                    uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg) {
     // per group of 8 slots: (F | cum << 16, symbol) of the symbol owning slot (g << 3): ONE LDS read resolves a slot whose group
     // lies inside one symbol's range (wide symbols: the probable ones), else a short forward scan over fc[] follows
     __shared__ uint2 coarse[1 << (MAXPB - 3)];
@@ -192,8 +191,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
     __shared__ uint32_t Fs[260];
     __shared__ uint32_t wring[512];
     __shared__ __align__(8) uint8_t oring[512];
-    const uint32_t j = blockIdx.x / c_count, c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63, par = lane & 1;
-    if (only_over == 2 && wdec[(uint64_t)j * 10 + c].kind != 2) return;  // wide mode: only what k_rans2_dec_prep left to this kernel
+    const uint32_t lane = threadIdx.x & 63, par = lane & 1;
     const DecTile d = info[j];
     if (d.type == 0 || d.type == TILE_BAD) return;
     const uint32_t vt = vtile(sel, j);
@@ -401,6 +399,35 @@ __global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__
 #undef XPNG_DEC_FLUSH
 #undef XPNG_DEC_REFILL
     XPNG_DSTAMP(2);
+}
+
+template <int MAXPB>
+__global__ __launch_bounds__(64) void k_rans2_decode(const DecTile *__restrict__ info,
+                                                     const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first,
+                                                     uint32_t c_count, int only_over, uint8_t *__restrict__ ctxsym,
+                                                     uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg) {
+    rans2_decode_stream<MAXPB>(info, tiles, sel, blockIdx.x / c_count, c_first + blockIdx.x % c_count, only_over, ctxsym, asym, dbg);
+}
+
+// Wide mode: the streams k_rans2_dec_prep left to the narrow form (kind 2 among the context streams: never written by the
+// reference).  A small fixed grid looks through the stream list 64 entries at a time - one workgroup per stream, as above, is
+// 46 656 workgroups asking for 38 KB of LDS each to find nothing, on the critical path between the context chains and the walk.
+template <int MAXPB>
+__global__ __launch_bounds__(64) void k_rans2_decode_rest(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+                                                          uint32_t total, uint32_t c_first, uint32_t c_count, uint8_t *__restrict__ ctxsym,
+                                                          uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg, const WDec *__restrict__ wdec) {
+    const uint32_t lane = threadIdx.x & 63, n = total * c_count;
+    for (uint32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+        const uint32_t idx = base + lane;
+        const bool mine = idx < n && wdec[(uint64_t)(idx / c_count) * 10 + c_first + idx % c_count].kind == 2;
+        uint64_t m = __ballot(mine);
+        while (m) {
+            const uint32_t id2 = sgpr(base + (uint32_t)__builtin_ctzll(m));
+            m &= m - 1;
+            rans2_decode_stream<MAXPB>(info, tiles, sel, id2 / c_count, c_first + id2 % c_count, 2, ctxsym, asym, dbg);
+            __syncthreads();
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1472,6 +1499,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
+    dbg_sequences()++;
     if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
     const uint64_t bpr = W * (uint64_t)pxsz;
     uint32_t free_ew, rthreads, rlds;
@@ -1486,24 +1514,25 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // Many tiles in flight: instruction issue is the bound, so the rANS chains run 32 streams to a wave (rans2_wide_dec.hpp);
     // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.
     const bool wide = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * spt > 2048 || getenv("XPNG_WIDE_RANS"));
+    const size_t pad_ch = getenv("XPNG_PAD_CHAIN") ? (size_t)atoi(getenv("XPNG_PAD_CHAIN")) : 0;
     constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 32;
     const uint32_t groups = (total + WD_CTX_STREAMS - 1) / WD_CTX_STREAMS, agroups = (total + WD_ALPHA_STREAMS - 1) / WD_ALPHA_STREAMS;
-    if (wide) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
+    if (wide) if (!dbg_skip("dec_prep")) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
     // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
-        if (wide && !getenv("XPNG_NARROW_ALPHA")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, 0, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        if (wide && !getenv("XPNG_NARROW_ALPHA")) { if (!dbg_skip("dec_chain_a")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, pad_ch, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym); }
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
         const size_t pad_al = getenv("XPNG_PAD_AL") ? (size_t)atoi(getenv("XPNG_PAD_AL")) : 0;
-        if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
+        if (dbg_skip("dec_alpha")) {} else if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
     if (wide) {
-        k_rans2_dec_chain<false, WD_CTX_STREAMS, false><<<groups * 9, 64, 0, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        if (!dbg_skip("dec_chain_c")) k_rans2_dec_chain<false, WD_CTX_STREAMS, false><<<groups * 9, 64, pad_ch, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         // context streams the small layout cannot hold (PROB_BITS > 12 or more than 16 symbols: never written by the reference)
-        k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 2, ws.d_ctxsym, ws.d_asym, dbg, ws.d_wdec);
+        if (!dbg_skip("dec_odd")) k_rans2_decode_rest<15><<<128, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, 0, 9, ws.d_ctxsym, ws.d_asym, dbg, ws.d_wdec);
     } else {
         k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
@@ -1535,16 +1564,16 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                 return bad("stream/event creation failed");
         }
         if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
-        k_dec_walk_wide<<<(total - jb + 63) / 64, 64, 0, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + 63) / 64, 64, pad_ch, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
-        if (getenv("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
-        else k_dec_walk<<<jb, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
+        if (dbg_skip("walk_big")) {} else if (getenv("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
-            k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<4><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
+            if (!dbg_skip("resid_small")) k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
+            if (!dbg_skip("recon_small")) k_dec_recon_band<4><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
         } else {
             k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
             k_dec_recon_band<3><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
@@ -1555,9 +1584,9 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4) {
         if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
-        if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        if (dbg_skip("resid_big")) {} else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<4><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
+        if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {

@@ -299,6 +299,7 @@ static int launch_chooser(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};
     const uint64_t bpr = c->W * PXSZ;
+    if (dbg_skip("chooser")) return 0;
     if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
     else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
     const uint32_t strips = 16;
@@ -322,7 +323,7 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (PXSZ == 4 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
+        if (!dbg_skip("transform")) k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
     } else if (PXSZ == 3 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
         k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
@@ -354,6 +355,7 @@ extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *con
 
 template <int PXSZ>
 static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
+    dbg_sequences()++;
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
@@ -381,8 +383,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
     }
     auto alpha_branch = [&](hipStream_t as) -> int {  // alpha plane -> tables -> chains, on the side stream
-        k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        k_rans2_chain2<true><<<(total + 31) / 32, 64, 0, as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
+        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, env_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
         return 0;
     };
@@ -411,21 +413,21 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         if (alpha_branch(c->enc_side)) return 1;
     }
     if (!fused) {
-        if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+        if (dbg_skip("streams")) {} else if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
         else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     }
     if (narrow) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, 0, s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
+        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, env_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
-        k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
+        if (!dbg_skip("finish")) k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
     k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
-    k_tile_gather<<<total, 256, pad_ga, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_ctx_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
+    if (!dbg_skip("gather")) k_tile_gather<<<total, 256, pad_ga, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_ctx_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
     return 0;
