@@ -46,7 +46,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         if mode != "enc": sl["ctx"].decode_device_batch(1, sl["bp"], lens, None, sl["op"], stream=sh)
     for k in range(2 * P): step(k)
     torch.cuda.synchronize()
-    steps = 20
+    stagger_ms = float(os.environ.get("KNOCKOUT_STAGGER_MS", "0"))  # slot i starts i x this much later (phase experiment)
+    if stagger_ms:
+        for i, sl in enumerate(slots):
+            with torch.cuda.stream(sl["stream"]):
+                torch.cuda._sleep(int(i * stagger_ms * 2.4e6))
+    steps = int(os.environ.get("KNOCKOUT_STEPS", "20"))
     t0 = time.perf_counter()
     for k in range(steps): step(k)
     torch.cuda.synchronize()
