@@ -82,11 +82,20 @@ __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restri
     }
     __syncthreads();
     const bool small = w1d_small(slot);
-    const uint32_t fcn = small ? WdLayout<false>::FCN : WdLayout<true>::FCN, co_off = 4 * (fcn + 1);
-    const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayout<true>::CBITS;
+    // big-alphabet slots: 16-bit cumulative counts cum[0 .. N] (cum[N] = 2^pb, 0x8000 behind it: greater than any slot) and 2^9
+    // coarse bytes - the byte layout of rans2_wide_dec.hpp's WdLayoutA, but indexed by the SLOT (residual alphabets are not
+    // skewed enough for the cold-rank form to pay: measured 108 ms against 76 per 32 images).  1 KB of LDS per resident stream
+    // instead of 2 KB: a chain wave holds its 32 tables for its whole life, and LDS is what the pipelined slots run out of first.
+    const uint32_t co_off = small ? WdLayout<false>::CO_OFF : WdLayoutA::CO_OFF;
+    const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayoutA::CBITS;
     uint8_t *gt = dtab + ((uint64_t)j * M2_SLOTS + slot) * WD_TAB_MAX;
-    uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
-    for (uint32_t i = lane; i <= fcn; i += 64) gfc[i] = i < Nnom ? fc[i] : 0xFFFFu;
+    if (small) {
+        uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
+        for (uint32_t i = lane; i <= WdLayout<false>::FCN; i += 64) gfc[i] = i < Nnom ? fc[i] : 0xFFFFu;
+    } else {
+        uint16_t *gcu = reinterpret_cast<uint16_t *>(gt);
+        for (uint32_t i = lane; i <= WdLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < Nnom ? fc[i] >> 16 : (i == Nnom ? 1u << pb : 0x8000u));
+    }
     {   // coarse slot -> symbol
         const uint32_t sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
         for (uint32_t g0 = lane * 4; g0 < entries; g0 += 256) {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restri
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restrict__ info, uint32_t total, const WDec *__restrict__ wdec,
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ scratch2) {
-    typedef WdLayout<BIG> L;
+    typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
     constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, RING = L::RING, KIND = BIG ? 2 : 1, STREAMS = 32, NSLOT = BIG ? 7 : 11;
     constexpr uint32_t TSTRIDE = TAB + 4;
     constexpr uint32_t PER = RING / 8;            // words one lane requests per boundary
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
         const uint32_t jj = grp * STREAMS + ts;
         uint32_t *dst = reinterpret_cast<uint32_t *>(ltab + ts * TSTRIDE);
         if (jj >= total || sgpr(wdec[(uint64_t)jj * M2_SLOTS + slot].kind) != KIND) {
-            for (uint32_t i = lane; i < TAB / 4; i += 64) dst[i] = i <= L::FCN ? 0xFFFFu : 0u;
+            // no chain in this slot: its lanes idle through the loop, but their table lookups must still terminate
+            for (uint32_t i = lane; i < TAB / 4; i += 64) dst[i] = i < L::CO_OFF / 4 ? (BIG ? (i ? 0x80008000u : 0x80000000u) : 0xFFFFu) : 0u;
             continue;
         }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dtab + ((uint64_t)jj * M2_SLOTS + slot) * WD_TAB_MAX);
@@ -201,10 +211,12 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
             cum = pick32(b3, c8, cum); nxt = pick32(b3, c9, nxt);
             F = nxt - cum; off = slot_ - cum;
         } else {
+            typedef uint32_t u32_a2 __attribute__((aligned(2)));
+            typedef __attribute__((address_space(3))) u32_a2 lds32u;
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot_ >> csh));
-            uint32_t e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym);
-            while (slot_ - (e >> 16) >= (e & 0xFFFFu)) { sym++; e = *(const lds32 *)(uintptr_t)(a_fc + 4 * sym); }  // entries >= N stop it
-            F = e & 0xFFFFu; off = slot_ - (e >> 16);
+            uint32_t e = *(const lds32u *)(uintptr_t)(a_fc + 2 * sym);  // cum[sym] | cum[sym + 1] << 16
+            while (slot_ >= (e >> 16)) { sym++; e = *(const lds32u *)(uintptr_t)(a_fc + 2 * sym); }  // cum[N] = 2^pb (and 0x8000 behind it) stops it
+            F = (e >> 16) - (e & 0xFFFFu); off = slot_ - (e & 0xFFFFu);
         }
         if (!act) { F = ident; off = slot_; }
         const uint32_t qlo = __builtin_amdgcn_alignbit(shi, slo, pb), qhi = shi >> pb;  // s >> pb
