@@ -340,7 +340,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the RGB legs of config 3")
     ap.add_argument("--no-config4", action="store_true", help="skip the 16384^2 strong-scaling leg")
     ap.add_argument("--roofline-reps", type=int, default=50)
-    ap.add_argument("--pipeline", type=int, default=5,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="contexts (each with its own HIP stream and buffers) that consecutive steps alternate between, so the "
                          "encode of step k+1 runs beside the decode of step k; 1 = strictly serial steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")
