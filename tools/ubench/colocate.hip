@@ -1,0 +1,74 @@
+// Do latency-bound single-wave workgroups slow each other down when several share a CU?  G one-wave workgroups (each holding LDS_KB of
+// LDS, like a chain wave) run a fixed number of dependent steps of ONE kind; ideal: time independent of G while every wave has a
+// SIMD to itself (G <= 1024).  Kinds: 0 dependent VALU, 1 dependent LDS read (ds_read_b32 -> address), 2 LDS read (b128) + VALU mix
+// like a decode step, 3 = 2 + one global 16-byte load and store per 8 steps, 4 = SALU chain (s_movrels), 5 = v_readlane -> SALU -> VALU.
+// build: hipcc -O3 --offload-arch=gfx950 colocate.hip -o colocate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define R4(x) x x x x
+#define R16(x) R4(R4(x))
+template <int KIND>
+__global__ __launch_bounds__(64) void k(uint32_t *out, const uint4 *src, uint4 *dst, int iters, uint32_t a) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    for (int i = lane; i < 2048; i += 64) lds[i] = ((i * 37 + a) & 2047) * 4;
+    __syncthreads();
+    uint32_t x = lane * 4, y = a | 1, acc = 0;
+    uint32_t s0 = a;
+    const uint4 *sp = src + (size_t)blockIdx.x * 4096 + lane;
+    uint4 *dp = dst + (size_t)blockIdx.x * 4096 + lane;
+    uint4 g = sp[0];
+    for (int i = 0; i < iters; i++) {
+        if (KIND == 0) { R16(asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x) : "v"(y));) }
+        if (KIND == 1) { R16(asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)" : "+v"(x));) }
+        if (KIND == 2 || KIND == 3) {
+            R16(asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n v_mad_u32_u24 %1, %0, %2, %1\n v_xor_b32 %1, %1, %0\n v_mad_u32_u24 %1, %1, %2, %0\n v_and_b32 %0, 0x1ffc, %0" : "+v"(x), "+v"(acc) : "v"(y));)
+            if (KIND == 3) {
+                const uint4 n = sp[(i + 1) & 4095 ? 64 * ((i + 1) & 63) : 0];
+                dp[64 * (i & 63)] = g;
+                acc += g.x;
+                g = n;
+            }
+        }
+        if (KIND == 4) { R16(asm volatile("s_lshl_b32 m0, %0, 1\n s_nop 0\n s_movrels_b32 %0, s40\n s_and_b32 %0, %0, 3" : "+s"(s0) : : "m0", "scc");) }
+        if (KIND == 5) { R16(asm volatile("v_readlane_b32 %1, %0, 3\n s_and_b32 %1, %1, 0xffff\n v_add_u32 %0, %1, %0" : "+v"(x), "+s"(s0) : : "scc");) }
+    }
+    if (x + acc + s0 == 0x12345) out[0] = x;
+}
+template <int KIND> static void run(const char *name, int lds_kb, uint32_t *out, uint4 *a, uint4 *b) {
+    const int iters = KIND == 0 ? 40000 : KIND == 4 ? 20000 : 10000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-34s LDS %2d KB:", name, lds_kb);
+    float base = 0;
+    for (int G : {64, 256, 512, 1024, 2048, 4096}) {
+        if ((long)G * lds_kb > 256L * 160 * 1) { /* more than fits at once: still run, it just queues */ }
+        k<KIND><<<G, 64, lds_kb * 1024>>>(out, a, b, 100, 3);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        k<KIND><<<G, 64, lds_kb * 1024>>>(out, a, b, iters, 3);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (G == 64) base = ms;
+        printf("  G=%d %.2f ms (%.2fx)", G, ms, ms / base);
+    }
+    printf("\n");
+}
+int main() {
+    uint32_t *out; uint4 *a, *b;
+    hipMalloc(&out, 64); hipMalloc(&a, (size_t)4096 * 4096 * 16); hipMalloc(&b, (size_t)4096 * 4096 * 16);
+    hipMemset(a, 1, (size_t)4096 * 4096 * 16);
+    // clocks up
+    for (int i = 0; i < 3; i++) { k<0><<<4096, 64, 8192>>>(out, a, b, 40000, 3); hipDeviceSynchronize(); }
+    run<0>("dependent VALU", 36, out, a, b);
+    run<1>("dependent LDS read", 36, out, a, b);
+    run<2>("LDS read + 4 VALU", 36, out, a, b);
+    run<2>("LDS read + 4 VALU", 8, out, a, b);
+    run<3>("LDS + VALU + global ld/st per step", 36, out, a, b);
+    run<4>("SALU movrels chain", 8, out, a, b);
+    run<5>("readlane -> SALU -> VALU", 8, out, a, b);
+    return 0;
+}
