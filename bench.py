@@ -376,7 +376,7 @@ def main():
         # memory and a down-clocked part, and its bandwidth-bound roofline pair reads 0.31-0.36 instead of the 0.55 of a clean run
         env.torch.cuda.empty_cache()
         for name, lvl in (("rgb_l1", 1), ("rgb_l2", 2)):
-            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 32)), "--pipeline", str(min(P, 3)),
+            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 32)), "--pipeline", str(min(P, 4)),
                    "--steps", str(max(6, args.steps // 3)), "--warmup", "2", "--roofline-reps", str(max(10, args.roofline_reps // 2)), "--no-legs", "--no-config4"]
             if args.no_cpu:
                 cmd.append("--no-cpu")

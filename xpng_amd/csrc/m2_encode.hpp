@@ -37,18 +37,20 @@ __host__ __device__ inline uint64_t m2_off_stream(uint32_t n, uint32_t s) {
     if (s < 17) return 11 * m2_small(n) + (uint64_t)(s - 11) * m2_big(n);           // class 3..8
     return 11 * m2_small(n) + (uint64_t)(s - 17) * m2_small(n);                     // gray candidates overlay class >= 3
 }
-__host__ __device__ inline uint64_t m2_blk_cap(uint32_t n, uint32_t s) {  // emitted words (<= 15 bits / symbol) + slack
-    const uint64_t syms = (s >= 11 && s < 17) ? 3ull * n : n;
-    return rup(2 * syms + 512, 256);
-}
-__host__ __device__ inline uint64_t m2_off_blk(uint32_t n, uint32_t s) {
+// Block slots (the words a stream's rANS chain emits: <= 15 bits per symbol, + states and slack) are laid out back to back, each
+// sized by ITS stream's symbol count cnt[k] (known once k_m2_streams / k_m2_gray_syms have run), not by the stream's capacity: a
+// colour tile's 17 streams hold at most n context + 3 n class symbols together, a gray tile's four candidates n each, so the region
+// is 8 n bytes + slack instead of the 58 n of one worst-case slot per stream (5.7 -> 2.6 GB of workspace per 4096^2 image).
+__host__ __device__ inline uint64_t m2_blk_cap(uint32_t m) { return rup(2ull * m + 512, 256); }
+__host__ __device__ inline uint64_t m2_blk_region(uint32_t n) { return rup(8ull * n + 21 * 768, 256); }
+__host__ __device__ inline uint64_t m2_off_blk(uint32_t n, const uint32_t *cnt, uint32_t s) {  // cnt: the tile's M2_SLOTS stream lengths
     uint64_t o = 11 * m2_small(n) + 6 * m2_big(n);
-    if (s >= 17) { o += 11 * m2_blk_cap(n, 0); return o + (uint64_t)(s - 17) * m2_blk_cap(n, 17); }  // gray overlay class >= 3 blocks
-    for (uint32_t k = 0; k < s; k++) o += m2_blk_cap(n, k);
+    if (s >= 17) return o + (uint64_t)(s - 17) * m2_blk_cap(n);  // gray candidates (a gray tile has no colour blocks)
+    for (uint32_t k = 0; k < s; k++) o += m2_blk_cap(cnt[k]);
     return o;
 }
 __host__ __device__ inline uint64_t m2_off_piece(uint32_t n, uint32_t s) {  // table bits of stream s: <= 256 * 16 bits
-    return m2_off_blk(n, 16) + m2_blk_cap(n, 16) + (uint64_t)s * 640;
+    return 11 * m2_small(n) + 6 * m2_big(n) + m2_blk_region(n) + (uint64_t)s * 640;
 }
 __host__ __device__ inline uint64_t m2_off_bits(uint32_t n) { return m2_off_piece(n, M2_SLOTS); }
 __host__ __device__ inline uint64_t m2_bits_cap(uint32_t n) { return rup(3ull * n + 21 * 640 + 256, 256); }
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(64) void k_rans1_encode(const TileDesc *__restrict_
     const uint32_t n = sgpr(stream_n[(uint64_t)tile * M2_SLOTS + slot]);
     const uint32_t Nnom = m2_nominal(slot);
     const int pb = slot >= 17 ? 15 : 14;
-    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t.n, slot));
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot));
     M2Blk *mb = blk + (uint64_t)tile * M2_SLOTS + slot;
     if (n == 0) {  // libxpng.c:167
         if (lane == 0) *mb = M2Blk{0, 0, 0, 0};
@@ -523,11 +525,13 @@ __global__ __launch_bounds__(256) void k_m2_gather(const uint8_t *const *__restr
     uint32_t o = 4 + bsz;
     if (r.kind == 2) {
         const uint32_t s = 17 + r.m;
-        m2_write_block(dst + o, b[s], reinterpret_cast<const uint32_t *>(sc + m2_off_blk(t.n, s)));
+        m2_write_block(dst + o, b[s], reinterpret_cast<const uint32_t *>(sc + m2_off_blk(t.n, nullptr, s)));
     } else {
+        uint64_t bo = m2_off_blk(t.n, nullptr, 0);  // block slots back to back, each sized by its stream's length (= M2Blk::n)
         for (uint32_t s = 0; s < M2_STREAMS; s++) {
-            m2_write_block(dst + o, b[s], reinterpret_cast<const uint32_t *>(sc + m2_off_blk(t.n, s)));
+            m2_write_block(dst + o, b[s], reinterpret_cast<const uint32_t *>(sc + bo));
             o += m2_blk_bytes(b[s]);
+            bo += m2_blk_cap(b[s].n);
         }
     }
 }

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     }
     Cmax = sgpr(Cmax); Cfull = sgpr(Cfull);
     const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
-    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t->n, slot));
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t->n, stream_n + (uint64_t)tile * M2_SLOTS, slot));
     uint32_t *w = out + 4;
     uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
     const uint32_t cmpl_base = 1u << pb;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64) void k_rans1_finish(const TileDesc *__restrict_
     const uint32_t n = stream_n[(uint64_t)tile * M2_SLOTS + slot];
     const uint32_t Nnom = m2_nominal(slot), N = p.N, distinct = p.distinct, cnt = p.cnt;
     const int pb = slot >= 17 ? 15 : 14;
-    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t.n, slot));
+    uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot));
     M2Blk *mb = blk + (uint64_t)tile * M2_SLOTS + slot;
     if (lane < 2) { out[2 * lane] = (uint32_t)p.st[lane]; out[2 * lane + 1] = (uint32_t)(p.st[lane] >> 32); }  // state0 then state1 (libxpng.c:245)
     // ---- type decision and the table piece (libxpng.c:247-259)
