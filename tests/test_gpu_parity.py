@@ -695,3 +695,33 @@ def test_context_stream_with_more_probability_bits_on_the_wide_path(gpu, po, mon
     out = bytes(out)
     assert np.array_equal(po.decode_tiles(1, out, W, H, 3), raster)        # the crafted file is a valid one
     assert np.array_equal(api.decode_tiles(1, out, W, H, 3), raster)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(1003, 777, 4), (453, 130, 4), (70, 200, 4), (1003, 777, 3), (17, 300, 4)])
+def test_band_reconstruction_row_staging_at_every_alignment(gpu, po, monkeypatch, geom):
+    """The wide decode's band reconstruction moves rows through LDS in 64-byte-aligned chunks (recon_band_core): chunk phases depend
+    on where a tile row starts in the raster and in the residual plane, and a row's first / last chunk leave word by word.  Odd
+    widths (row pitch not a multiple of 64 bytes), tiles narrower than one chunk, and destination rasters at each 16-byte phase of a
+    64-byte line: decode on the device, compare with the input raster, and check that nothing around the raster
+    was written."""
+    import torch
+    monkeypatch.setenv("XPNG_WIDE_RANS", "1")
+    from xpng_amd.synth import synth_raster
+    W, H, ch = geom
+    raster = synth_raster("photo", W, H, ch == 4, seed=W + H).copy()
+    if ch == 4:
+        raster[raster[..., 3] == 0] = 0
+    blobs = po.encode_tiles(1, raster)
+    ctx = gpu.Context(W, H, ch)
+    d_blob = torch.from_numpy(np.frombuffer(blobs + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+    nbytes = W * H * ch
+    for shift in (0, 16, 32, 48):   # (the C-ABI asks for 16-byte aligned device buffers; the odd row pitch supplies every 4-byte phase)
+        buf = torch.full((nbytes + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+        ctx.decode_device(1, d_blob.data_ptr(), len(blobs), None, buf.data_ptr() + 64 + shift)
+        torch.cuda.synchronize()
+        assert ctx.decode_status() == 0
+        out = buf.cpu().numpy()
+        assert np.array_equal(out[64 + shift:64 + shift + nbytes].reshape(H, W, ch), raster), (geom, shift)
+        assert (out[:64 + shift] == 0xA5).all() and (out[64 + shift + nbytes:] == 0xA5).all(), (geom, shift)
+    ctx.close()
