@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64) void k_m2_dec_walk(const M2DecTile *__restrict_
 
 // --------------------------------------------------------------------------------------------------
 // residual words per pixel.  colour: class streams by nl (DEC_, libxpng.c:901-910) + green add-back; gray: the single stream.
-__global__ __launch_bounds__(1024) void k_m2_dec_resid(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                        const uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
                                                        const uint8_t *__restrict__ nlseq, uint32_t *__restrict__ resid) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_m2_dec_resid(const M2DecTile *__restri
     uint32_t *rs = resid + t.pbase;
     if (d.kind == 2) {
         const uint8_t *st = sc + m2_off_stream(t.n, 17);
-        for (uint32_t i = tid; i < t.n; i += 1024) {
+        for (uint32_t i = tid; i < t.n; i += THREADS) {
             uint32_t w = 0;
             if (i) { const uint32_t v = (uint32_t)zz_dec(st[i - 1]) & 255u; w = v | (v << 8) | (v << 16) | (1u << 24); }
             rs[i] = w;
@@ -317,11 +318,11 @@ __global__ __launch_bounds__(1024) void k_m2_dec_resid(const M2DecTile *__restri
     }
     const uint8_t *nls = nlseq + t.pbase;
     const int useG = d.m & 1;
-    __shared__ uint32_t s_wave[16][9], s_run[9];
+    __shared__ uint32_t s_wave[THREADS / 64][9], s_run[9];
     if (tid < 9) s_run[tid] = 0;
     __syncthreads();
     const uint64_t lt = lanemask_lt();
-    for (uint32_t i0 = 0; i0 < t.n; i0 += 1024) {
+    for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
         const uint32_t i = i0 + tid;
         const bool coded = i < t.n && i > 0;
         const uint32_t nl = coded ? nls[i - 1] : 0;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_m2_dec_resid(const M2DecTile *__restri
             rs[i] = word;
         }
         uint32_t tot = 0;
-        if (tid >= 1 && tid < 9) for (int w2 = 0; w2 < 16; w2++) tot += s_wave[w2][tid];
+        if (tid >= 1 && tid < 9) for (int w2 = 0; w2 < THREADS / 64; w2++) tot += s_wave[w2][tid];
         __syncthreads();
         if (tid >= 1 && tid < 9) s_run[tid] += tot;
         __syncthreads();
@@ -466,7 +467,8 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
     } else if (m2_wide_decode(ws, B, n_tiles, total, d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, s, err)) return 1;
     k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);
-    k_m2_dec_resid<<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
+    if ((uint64_t)total * M2_STREAMS > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m2_dec_resid<256><<<total, 256, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
+    else k_m2_dec_resid<1024><<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
     const bool wide_recon = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * M2_STREAMS > 2048 || getenv("XPNG_WIDE_RANS")) && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON");

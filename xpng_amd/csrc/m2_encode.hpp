@@ -90,8 +90,11 @@ __global__ __launch_bounds__(256) void k_m2_classify(const uint8_t *const *__res
 }
 
 // --------------------------------------------------------------------------------------------------
-// routing for colour tiles: context streams by pl (as k_m1_streams) and class streams by nl.  grid = tiles, block = 1024.
-__global__ __launch_bounds__(1024) void k_m2_streams(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
+// routing for colour tiles: context streams by pl (as k_m1_streams) and class streams by nl.  grid = tiles, block = THREADS
+// (1024 for one image: the tile's latency; 256 for batches: four barriers per 256-pixel step cost less among 4 waves than among 16,
+// and eight workgroups share a CU instead of two).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
                                                      uint32_t *__restrict__ stream_n) {
@@ -103,13 +106,13 @@ __global__ __launch_bounds__(1024) void k_m2_streams(const TileDesc *__restrict_
     const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;
     uint8_t *sc = scratch2 + sbase2[tile];
     __shared__ uint32_t s_run_ctx[9], s_run_cls[9];
-    __shared__ uint32_t s_wave_ctx[16][9], s_wave_cls[16][9];
-    __shared__ uint32_t s_wave_last[16];
+    __shared__ uint32_t s_wave_ctx[THREADS / 64][9], s_wave_cls[THREADS / 64][9];
+    __shared__ uint32_t s_wave_last[THREADS / 64];
     if (tid < 9) { s_run_ctx[tid] = 0; s_run_cls[tid] = 0; }
     __syncthreads();
     uint32_t run_pl = 0;
     const uint64_t lt = lanemask_lt();
-    for (uint32_t i0 = 0; i0 < t.n; i0 += 1024) {
+    for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
         const uint32_t i = i0 + tid;
         const uint32_t nlv = i < t.n ? pnl[i] : NL_NONE;
         const bool coded = nlv != NL_NONE;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(1024) void k_m2_streams(const TileDesc *__restrict_
         if (lane >= 1 && lane < 9) s_wave_cls[wv][lane] = cls_cnt;
         __syncthreads();  // (A)
         uint32_t carry = run_pl, new_run_pl = run_pl;
-        for (int w2 = 0; w2 < 16; w2++) {
+        for (int w2 = 0; w2 < THREADS / 64; w2++) {
             const uint32_t wl = s_wave_last[w2];
             if (w2 < (int)wv && wl != NL_NONE) carry = wl;
             if (wl != NL_NONE) new_run_pl = wl;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_m2_streams(const TileDesc *__restrict_
             }
         }
         uint32_t tot_ctx = 0, tot_cls = 0;
-        if (tid < 9) for (int w2 = 0; w2 < 16; w2++) { tot_ctx += s_wave_ctx[w2][tid]; if (tid) tot_cls += s_wave_cls[w2][tid]; }
+        if (tid < 9) for (int w2 = 0; w2 < THREADS / 64; w2++) { tot_ctx += s_wave_ctx[w2][tid]; if (tid) tot_cls += s_wave_cls[w2][tid]; }
         __syncthreads();  // (C)
         if (tid < 9) { s_run_ctx[tid] += tot_ctx; s_run_cls[tid] += tot_cls; }
         run_pl = new_run_pl;
