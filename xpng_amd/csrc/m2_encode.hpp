@@ -172,6 +172,7 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
 }
 
 // --------------------------------------------------------------------------------------------------
+constexpr uint32_t M2_GRAY_REPS = 16;
 // gray tiles: the four candidate symbol streams (libxpng.c:597-604).  grid = tiles * blocks_per_tile, block = 256.
 __global__ __launch_bounds__(256) void k_m2_gray_syms(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                       const TileDesc *__restrict__ tiles, TileSel sel, uint32_t bpt,
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256) void k_m2_gray_syms(const uint8_t *const *__re
     const uint8_t *raster = rasters[t.img];
     uint8_t *sc = scratch2 + sbase2[tile];
     if (chunk == 0 && threadIdx.x < 4) stream_n[(uint64_t)tile * M2_SLOTS + 17 + threadIdx.x] = t.n - 1;
-    const uint32_t i = chunk * 256 + threadIdx.x + 1;  // pixel 1..n-1 -> symbol i-1
+    for (uint32_t rep = 0; rep < M2_GRAY_REPS; rep++) {  // (4096 pixels per workgroup: a colour image launches these to find nothing)
+    const uint32_t i = (chunk * M2_GRAY_REPS + rep) * 256 + threadIdx.x + 1;  // pixel 1..n-1 -> symbol i-1
     if (i >= t.n) return;
     const uint32_t y = i / t.w, x = i - y * t.w;
     const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * 3;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256) void k_m2_gray_syms(const uint8_t *const *__re
     sc[m2_off_stream(t.n, 18) + i - 1] = (uint8_t)s1;
     sc[m2_off_stream(t.n, 19) + i - 1] = (uint8_t)s2;
     sc[m2_off_stream(t.n, 20) + i - 1] = (uint8_t)s3;
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
