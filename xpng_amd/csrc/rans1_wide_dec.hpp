@@ -241,14 +241,12 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending when the loop is entered (see k_rans2_dec_chain)
     for (uint32_t tb = 0; tb < T; tb += 8) {
         const uint32_t wi0 = wi;
+        // v1 decodes FORWARDS and every lane starts at pair 0, so nothing has to be held back: a lane past the end of its stream
+        // (or without one) just keeps stepping on whatever its state and its clamped ring hold - its symbols are not stored (the
+        // block store below is gated), its requests are clamped at the stream's last word - and the odd tail symbol (libxpng.c:300:
+        // one more from state0, no refill) is out of the state before the refill it does not need.  No predicates in the steps.
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t t = tb + (uint32_t)u;
-            const bool pair_act = t < pairs;
-            const bool tail = t == pairs && (n & 1u) && par == 0;  // libxpng.c:300: one more symbol from state0, no refill
-            const uint32_t sym = step(pair_act || tail, pair_act, 2 * (uint32_t)u + par);
-            if (tail) out[n - 1] = (uint8_t)sym;
-        }
+        for (int u = 0; u < 8; u++) step(true, true, 2 * (uint32_t)u + par);
         rw += (wi - wi0) & (RING - 1);
         {   // in-flight words land (unconditional, like the request below: fhi == 0 when nothing was requested)
             const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, PER > 4 ? q1.x : qx, q1.y, q1.z, q1.w, qx};
