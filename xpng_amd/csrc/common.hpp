@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -11,12 +12,12 @@ namespace xpng {
 // Knock-out switch for timing studies (tools/knockout.py): XPNG_SKIP=name,name,... leaves the named kernels of the batched
 // level-1 paths unlaunched once XPNG_SKIP_AFTER launch sequences have run complete (the workspaces then still hold the
 // previous, identical results, so everything downstream keeps working on valid data).  Never set in production.
-inline uint64_t &dbg_sequences() { static uint64_t n = 0; return n; }
+inline std::atomic<uint64_t> &dbg_sequences() { static std::atomic<uint64_t> n{0}; return n; }  // (callers may come from several host threads)
 inline bool dbg_skip(const char *name) {
     static const char *list = getenv("XPNG_SKIP");
     if (!list) return false;
     static const uint64_t after = getenv("XPNG_SKIP_AFTER") ? strtoull(getenv("XPNG_SKIP_AFTER"), nullptr, 10) : 16;
-    if (dbg_sequences() <= after) return false;
+    if (dbg_sequences().load(std::memory_order_relaxed) <= after) return false;
     const size_t n = strlen(name);
     for (const char *p = list; (p = strstr(p, name)); p += n)
         if ((p == list || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;

@@ -1499,7 +1499,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
-    dbg_sequences()++;
+    dbg_sequences().fetch_add(1, std::memory_order_relaxed);
     if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
     const uint64_t bpr = W * (uint64_t)pxsz;
     uint32_t free_ew, rthreads, rlds;

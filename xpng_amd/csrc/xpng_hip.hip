@@ -355,7 +355,7 @@ extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *con
 
 template <int PXSZ>
 static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
-    dbg_sequences()++;
+    dbg_sequences().fetch_add(1, std::memory_order_relaxed);
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
