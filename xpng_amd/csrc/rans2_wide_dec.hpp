@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         const uint32_t sym = step(par == 0, (n - 1) & 15u);
         if (par == 0) out[n - 1] = (uint8_t)sym;
     }
-    uint32_t T = npairs, Tmin = npairs;
+    uint32_t T = npairs, Tmin = live ? npairs : 0xFFFFFFFFu;  // (a lane without a chain steps on the identity entry whatever the variant)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t v = __shfl_xor(T, o), v2 = __shfl_xor(Tmin, o);
