@@ -124,8 +124,7 @@ __device__ __forceinline__ uint32_t swar_zigzag8(uint32_t d) {  // per byte: v =
 // interior pixel (row > 0, column > 0): returns the zig-zag word (zr | zg<<8 | zb<<16 | za<<24) and nl.
 // col0: the pixel is in column 0 of its tile (row > 0): every channel predicts from U and the green subtraction is skipped
 // (libxpng.c:505-513; it applies to interior pixels only).
-template <int useGrad, int useG>
-__device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, uint32_t &nl, bool col0 = false) {
+__device__ __forceinline__ uint32_t m1_pixel_interior(const int useGrad, const int useG, uint32_t cur, uint32_t L, uint32_t U, uint32_t UL, uint32_t &nl, bool col0 = false) {
     uint32_t pred;
     if (!useGrad) {
         pred = __builtin_amdgcn_lerp(L, U, 0x01010101u);  // per byte (L + U + 1) >> 1   (p2a)
@@ -157,12 +156,11 @@ __device__ __forceinline__ uint32_t m1_pixel_interior(uint32_t cur, uint32_t L, 
 
 // four interior RGB pixels (left neighbour cp[0], pixels cp[1..4]; the five above them in up[]) through the byte-parallel
 // arithmetic: the alpha byte is set to 255 on both sides, so it predicts itself and leaves a zero residual
-template <int useGrad, int useG>
-__device__ __forceinline__ void rgb_group_interior(const uint32_t *cp, const uint32_t *up, uint32_t &onl, uint32_t &orr, uint32_t &og, uint32_t &ob) {
+__device__ __forceinline__ void rgb_group_interior(const int useGrad, const int useG, const uint32_t *cp, const uint32_t *up, uint32_t &onl, uint32_t &orr, uint32_t &og, uint32_t &ob) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t nl;
-        const uint32_t z = m1_pixel_interior<useGrad, useG>(cp[k + 1] | 0xFF000000u, cp[k] | 0xFF000000u, up[k + 1], up[k], nl);
+        const uint32_t z = m1_pixel_interior(useGrad, useG, cp[k + 1] | 0xFF000000u, cp[k] | 0xFF000000u, up[k + 1], up[k], nl);
         onl |= nl << (8 * k); orr |= (z & 255u) << (8 * k); og |= ((z >> 8) & 255u) << (8 * k); ob |= ((z >> 16) & 255u) << (8 * k);
     }
 }
@@ -197,12 +195,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
                                 __builtin_amdgcn_alignbyte(c.w, c.z, 1) & 0xFFFFFFu, c.w & 0xFFFFFFu};
         const uint32_t up[5] = {u.x & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.y, u.x, 3) & 0xFFFFFFu, __builtin_amdgcn_alignbyte(u.z, u.y, 2) & 0xFFFFFFu,
                                 __builtin_amdgcn_alignbyte(u.w, u.z, 1) & 0xFFFFFFu, u.w & 0xFFFFFFu};
-        switch (pr & 3) {  // (uniform: a workgroup works on one tile)
-            case 0: rgb_group_interior<0, 0>(cp, up, onl, orr, og, ob); break;
-            case 1: rgb_group_interior<0, 1>(cp, up, onl, orr, og, ob); break;
-            case 2: rgb_group_interior<1, 0>(cp, up, onl, orr, og, ob); break;
-            default: rgb_group_interior<1, 1>(cp, up, onl, orr, og, ob); break;
-        }
+        { const uint32_t pr_ = (pr & 3) & 3u; rgb_group_interior((int)(pr_ >> 1), (int)(pr_ & 1u), cp, up, onl, orr, og, ob); }  // (predictor flags are wave-uniform runtime values: one copy of the code, not four - the I-cache is shared by every kernel in flight)
     } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -234,8 +227,7 @@ constexpr uint32_t TR_ROWS = 8, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // 
 // phase 2 of k_m1_transform_rgba, specialised on the tile's predictor flags so that no per-pixel branch on them remains
 // one group of 4 consecutive pixels of a strip staged in LDS (RGBA): the five packed symbol dwords.  g = group index inside the
 // strip, (yy, x0) = row inside the strip and column of its first pixel.
-template <int useGrad, int useG>
-__device__ __forceinline__ void rgba_group(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first, uint32_t strip_px,
+__device__ __forceinline__ void rgba_group(const int useGrad, const int useG, const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first, uint32_t strip_px,
                                            uint32_t g, uint32_t yy, uint32_t x0, uint32_t &onl, uint32_t &orr, uint32_t &og, uint32_t &ob, uint32_t &oa) {
         const uint32_t j0 = g * 4;  // pixel index inside the strip
         uint32_t x = x0;
@@ -267,7 +259,7 @@ __device__ __forceinline__ void rgba_group(const uint8_t *rows, const TileDesc &
                 }
                 uint32_t z[4], n4[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior<useGrad, useG>(c[k + 1], c[k], u[k + 1], u[k], n4[k], col0[k]);
+                for (int k = 0; k < 4; k++) z[k] = m1_pixel_interior(useGrad, useG, c[k + 1], c[k], u[k + 1], u[k], n4[k], col0[k]);
                 onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
                 const uint32_t t01lo = __builtin_amdgcn_perm(z[1], z[0], 0x05010400u);  // z0.b0 z1.b0 z0.b1 z1.b1
                 const uint32_t t01hi = __builtin_amdgcn_perm(z[1], z[0], 0x07030602u);  // z0.b2 z1.b2 z0.b3 z1.b3
@@ -287,7 +279,7 @@ __device__ __forceinline__ void rgba_group(const uint8_t *rows, const TileDesc &
                     const uint32_t *rc = reinterpret_cast<const uint32_t *>(rows + ll * TR_PITCH + ((ph0 + ll * bl) & 15u));
                     const uint32_t *ru = reinterpret_cast<const uint32_t *>(rows + (ll - 1) * TR_PITCH + ((ph0 + (ll - 1) * bl) & 15u));
                     const uint32_t cur = rc[xx], L = xx ? rc[xx - 1] : 0u, U = ru[xx], UL = xx ? ru[xx - 1] : 0u;
-                    z[k] = m1_pixel_interior<useGrad, useG>(cur, L, U, UL, n4[k], xx == 0);
+                    z[k] = m1_pixel_interior(useGrad, useG, cur, L, U, UL, n4[k], xx == 0);
                     if (++xx == t.w) { xx = 0; ll++; }
                 }
                 onl = n4[0] | (n4[1] << 8) | (n4[2] << 16) | (n4[3] << 24);
@@ -321,8 +313,7 @@ __device__ __forceinline__ void rgba_group(const uint8_t *rows, const TileDesc &
         }
 }
 
-template <int useGrad, int useG>
-__device__ __forceinline__ void transform_phase2(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first,
+__device__ __forceinline__ void transform_phase2(const int useGrad, const int useG, const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first,
                                                  uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride) {
     const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
     // (row, column) of a thread's first group by one division, then advanced incrementally: +1024 pixels per iteration
@@ -331,7 +322,7 @@ __device__ __forceinline__ void transform_phase2(const uint8_t *rows, const Tile
     for (uint32_t g = threadIdx.x; g < groups; g += 256, yy += dy, x0 += dx) {
         if (x0 >= t.w) { x0 -= t.w; yy++; }
         uint32_t onl, orr, og, ob, oa;
-        rgba_group<useGrad, useG>(rows, t, bpr, y0, first, strip_px, g, yy, x0, onl, orr, og, ob, oa);
+        rgba_group(useGrad, useG, rows, t, bpr, y0, first, strip_px, g, yy, x0, onl, orr, og, ob, oa);
         const uint32_t j0 = g * 4;
         const uint64_t o = t.pbase + (uint64_t)y0 * t.w + j0;
         *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
@@ -407,12 +398,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
     }
     __syncthreads();
     // ---- phase 2 (dispatch once per workgroup on the tile's predictor flags)
-    switch (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) {
-        case 0: transform_phase2<0, 0>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
-        case 1: transform_phase2<0, 1>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
-        case 2: transform_phase2<1, 0>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
-        default: transform_phase2<1, 1>(rows, t, bpr, y0, first, nrows, planes, plane_stride); break;
-    }
+    { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) & 3u; transform_phase2((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, nrows, planes, plane_stride); }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -424,8 +410,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
 // byte forced to 255 on both sides (it predicts itself: zero residual).  Four planes, one aligned dword store each.
 constexpr uint32_t TR3_LDS_PAD = 16;  // the read of a column-0 group starts 3 bytes in front of its row
 // the same for RGB (four packed symbol dwords); g0b = global byte offset of the strip's first staged byte (its 16-byte phase)
-template <int useGrad, int useG>
-__device__ __forceinline__ void rgb_group(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint64_t g0, uint32_t y0, uint32_t first, uint32_t strip_px,
+__device__ __forceinline__ void rgb_group(const int useGrad, const int useG, const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint64_t g0, uint32_t y0, uint32_t first, uint32_t strip_px,
                                           uint32_t g, uint32_t yy, uint32_t x0, uint32_t &onl, uint32_t &orr, uint32_t &og, uint32_t &ob) {
     typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
     const uint32_t ph0 = (uint32_t)(g0 & 15), bl = (uint32_t)(bpr & 15);
@@ -451,13 +436,13 @@ __device__ __forceinline__ void rgb_group(const uint8_t *rows, const TileDesc &t
                                         __builtin_amdgcn_alignbyte(u.w, u.z, 1) & 0xFFFFFFu, u.w & 0xFFFFFFu};
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    z[k] = m1_pixel_interior<useGrad, useG>(cp[k + 1] | 0xFF000000u, cp[k] | 0xFF000000u, up[k + 1] | 0xFF000000u, up[k] | 0xFF000000u, n4[k], k == 0 && x == 0);
+                    z[k] = m1_pixel_interior(useGrad, useG, cp[k + 1] | 0xFF000000u, cp[k] | 0xFF000000u, up[k + 1] | 0xFF000000u, up[k] | 0xFF000000u, n4[k], k == 0 && x == 0);
             } else {            // a group that straddles two rows (tile width not a multiple of 4): pixel by pixel
                 uint32_t xx = x, ll = lr;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t cur = px_at(ll, xx), L = xx ? px_at(ll, xx - 1) : 0u, U = px_at(ll - 1, xx), UL = xx ? px_at(ll - 1, xx - 1) : 0u;
-                    z[k] = m1_pixel_interior<useGrad, useG>(cur | 0xFF000000u, L | 0xFF000000u, U | 0xFF000000u, UL | 0xFF000000u, n4[k], xx == 0);
+                    z[k] = m1_pixel_interior(useGrad, useG, cur | 0xFF000000u, L | 0xFF000000u, U | 0xFF000000u, UL | 0xFF000000u, n4[k], xx == 0);
                     if (++xx == t.w) { xx = 0; ll++; }
                 }
             }
@@ -484,8 +469,7 @@ __device__ __forceinline__ void rgb_group(const uint8_t *rows, const TileDesc &t
         }
 }
 
-template <int useGrad, int useG>
-__device__ __forceinline__ void transform_phase2_rgb(const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint64_t g0, uint32_t y0, uint32_t first,
+__device__ __forceinline__ void transform_phase2_rgb(const int useGrad, const int useG, const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint64_t g0, uint32_t y0, uint32_t first,
                                                      uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride) {
     const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
     uint32_t yy = (threadIdx.x * 4) / t.w, x0 = threadIdx.x * 4 - yy * t.w;
@@ -493,7 +477,7 @@ __device__ __forceinline__ void transform_phase2_rgb(const uint8_t *rows, const 
     for (uint32_t g = threadIdx.x; g < groups; g += 256, yy += dy, x0 += dx) {
         if (x0 >= t.w) { x0 -= t.w; yy++; }
         uint32_t onl, orr, og, ob;
-        rgb_group<useGrad, useG>(rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, onl, orr, og, ob);
+        rgb_group(useGrad, useG, rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, onl, orr, og, ob);
         const uint32_t j0 = g * 4;
         const uint64_t o = t.pbase + (uint64_t)y0 * t.w + j0;
         *reinterpret_cast<uint32_t *>(planes + 0 * plane_stride + o) = onl;
@@ -552,12 +536,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
         for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
     }
     __syncthreads();
-    switch (pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3) {
-        case 0: transform_phase2_rgb<0, 0>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
-        case 1: transform_phase2_rgb<0, 1>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
-        case 2: transform_phase2_rgb<1, 0>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
-        default: transform_phase2_rgb<1, 1>(rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); break;
-    }
+    { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3) & 3u; transform_phase2_rgb((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -876,20 +855,10 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_fused(const uint8_t *const *_
             if (g < groups) {
                 const uint32_t yy = (4 * g) / t.w, x0 = 4 * g - yy * t.w;
                 if constexpr (PXSZ == 4) {
-                    switch (pr) {  // (uniform)
-                        case 0: rgba_group<0, 0>(rows, t, bpr, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4, a4); break;
-                        case 1: rgba_group<0, 1>(rows, t, bpr, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4, a4); break;
-                        case 2: rgba_group<1, 0>(rows, t, bpr, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4, a4); break;
-                        default: rgba_group<1, 1>(rows, t, bpr, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4, a4); break;
-                    }
+                    { const uint32_t pr_ = (pr) & 3u; rgba_group((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4, a4); }  // (predictor flags are wave-uniform runtime values: one copy of the code, not four - the I-cache is shared by every kernel in flight)
                     if (aplane) *reinterpret_cast<uint32_t *>(aplane + t.pbase + (uint64_t)y0 * t.w + 4 * g) = a4;  // alpha symbols (nullptr: k_alpha_syms has written them)
                 } else {
-                    switch (pr) {
-                        case 0: rgb_group<0, 0>(rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4); break;
-                        case 1: rgb_group<0, 1>(rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4); break;
-                        case 2: rgb_group<1, 0>(rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4); break;
-                        default: rgb_group<1, 1>(rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4); break;
-                    }
+                    { const uint32_t pr_ = (pr) & 3u; rgb_group((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4); }  // (predictor flags are wave-uniform runtime values: one copy of the code, not four - the I-cache is shared by every kernel in flight)
                 }
             }
             // ---- the routing of k_m1_streams on (nl4, r4, g4, b4)
