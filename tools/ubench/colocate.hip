@@ -57,6 +57,28 @@ template <int KIND> static void run(const char *name, int lds_kb, uint32_t *out,
     }
     printf("\n");
 }
+// K kernels started at the same moment on K streams, G one-wave workgroups each (far fewer waves than SIMDs): do they pile up?
+template <int KIND> static void concurrent(const char *name, int lds_kb, int G, uint32_t *out, uint4 *a, uint4 *b) {
+    const int iters = KIND == 0 ? 40000 : 10000;
+    printf("%-22s LDS %2d KB, G=%d per kernel:", name, lds_kb, G);
+    float base = 0;
+    for (int K : {1, 2, 4, 6, 8}) {
+        std::vector<hipStream_t> st(K);
+        for (auto &x : st) hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipDeviceSynchronize();
+        float worst = 0;
+        std::vector<hipEvent_t> s0(K), s1(K);
+        for (int i = 0; i < K; i++) { hipEventCreate(&s0[i]); hipEventCreate(&s1[i]); }
+        for (int i = 0; i < K; i++) { hipEventRecord(s0[i], st[i]); k<KIND><<<G, 64, lds_kb * 1024, st[i]>>>(out, a, b, iters, 3); hipEventRecord(s1[i], st[i]); }
+        hipDeviceSynchronize();
+        for (int i = 0; i < K; i++) { float ms; hipEventElapsedTime(&ms, s0[i], s1[i]); worst = ms > worst ? ms : worst; }
+        if (K == 1) base = worst;
+        printf("  K=%d %.2f ms (%.2fx)", K, worst, worst / base);
+        for (auto &x : st) hipStreamDestroy(x);
+    }
+    printf("\n");
+}
 int main() {
     uint32_t *out; uint4 *a, *b;
     hipMalloc(&out, 64); hipMalloc(&a, (size_t)4096 * 4096 * 16); hipMalloc(&b, (size_t)4096 * 4096 * 16);
@@ -70,5 +92,9 @@ int main() {
     run<3>("LDS + VALU + global ld/st per step", 36, out, a, b);
     run<4>("SALU movrels chain", 8, out, a, b);
     run<5>("readlane -> SALU -> VALU", 8, out, a, b);
+    concurrent<0>("dependent VALU", 36, 41, out, a, b);
+    concurrent<2>("LDS read + 4 VALU", 36, 41, out, a, b);
+    concurrent<2>("LDS read + 4 VALU", 36, 162, out, a, b);
+    concurrent<0>("dependent VALU", 8, 162, out, a, b);
     return 0;
 }
