@@ -150,6 +150,12 @@ int xpnghip_m1_transform_device_batch(xpnghip_ctx *ctx, const void *const *d_ras
  *       30 = chooser cost sums (16 B).  Returns bytes written to `out` (<= cap) or -1. */
 int64_t xpnghip_debug_fetch(xpnghip_ctx *ctx, int what, uint64_t tile, void *out, uint64_t cap);
 
+/* ---- wave probe for placement studies (tools/wave_probe.py; no reference counterpart) ---------------
+ * Registers a device buffer of `cap` 32-byte records {u32 kernel, block, HW_ID, XCC_ID; u64 t0, t1 (100 MHz)}: wave 0 of every
+ * workgroup of the serial-chain kernels appends one when it ends.  d_buf == NULL switches the probe off. */
+int xpnghip_debug_probe(void *d_buf, uint32_t cap);
+int64_t xpnghip_debug_probe_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,32 @@
 
 namespace xpng {
 
+// Streams that carry serial-chain kernels.  tools/wave_probe.py shows that in the pipelined bench the chain WAVES run at their solo
+// speed while the chain KERNELS take 1.7x longer: their workgroups (tens of KB of LDS each) trickle onto CUs that bandwidth kernels
+// with 10^4..10^5 queued workgroups keep full.  Stream priority is the obvious lever and the wrong one:
+inline hipError_t chain_stream_create(hipStream_t *s) {
+    static const int prio = [] { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); return getenv("XPNG_STREAM_PRIORITY") ? hi : 0; }();  // (measured: 27.8 against 39.2 Gpx/s with the highest priority - the normal-priority queues starve while a priority kernel runs - so the default is 0)
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+}
+
+// Wave probe for placement studies (tools/wave_probe.py): when a buffer is registered (xpnghip_debug_probe), wave 0 of every
+// workgroup of the serial-chain kernels records where it ran (HW_ID: SE / CU / SIMD / wave slot; XCC_ID) and when (constant
+// 100 MHz clock).  One scalar load and a not-taken branch per kernel when no buffer is registered.
+struct WaveProbe { uint32_t kernel, block, hwid, xcc; uint64_t t0, t1; };
+__device__ WaveProbe *g_probe_buf = nullptr;
+__device__ uint32_t g_probe_cap = 0, g_probe_n = 0;
+#define XPNG_PROBE_BEGIN()                                                                        \
+    WaveProbe *const probe_buf_ = g_probe_buf;                                                    \
+    uint64_t probe_t0_ = 0;                                                                       \
+    if (probe_buf_) probe_t0_ = __builtin_amdgcn_s_memrealtime();
+#define XPNG_PROBE_END(kid)                                                                       \
+    if (probe_buf_ && threadIdx.x == 0) {                                                         \
+        const uint32_t pi_ = atomicAdd(&g_probe_n, 1u);                                           \
+        if (pi_ < g_probe_cap)                                                                    \
+            probe_buf_[pi_] = WaveProbe{(uint32_t)(kid), blockIdx.x, (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4),     \
+                                        (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20), probe_t0_, __builtin_amdgcn_s_memrealtime()}; \
+    }
+
 // Knock-out switch for timing studies (tools/knockout.py): XPNG_SKIP=name,name,... leaves the named kernels of the batched
 // level-1 paths unlaunched once XPNG_SKIP_AFTER launch sequences have run complete (the workspaces then still hold the
 // previous, identical results, so everything downstream keeps working on valid data).  Never set in production.

@@ -818,7 +818,9 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
     if (d.type == 0 || d.type == TILE_BAD) return;
     const TileDesc t = tiles[vtile(sel, j)];
     const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.ctx_start[9]);
+    XPNG_PROBE_BEGIN()
     ctx_walk_salu(ctxsym + t.pbase, lane < 9 ? d.ctx_start[lane] : 0, total, nlseq + t.pbase);  // (k_dec_parse aligns the queue starts to 16 bytes)
+    XPNG_PROBE_END(6)
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -841,6 +843,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;
     __shared__ uint32_t ringw[10 * WDW * 64];
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * 64 + lane;  // work items [j0, total_tiles)
     bool live = j < total_tiles;
     const DecTile *d = info + (live ? j : 0);
@@ -938,6 +941,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
         block(kb + 16);
         service(1);
     }
+    XPNG_PROBE_END(5)
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1505,7 +1509,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
     if (!ws.side) {
-        if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess ||
+        if (chain_stream_create(&ws.side) != hipSuccess ||
             hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess)
             return bad("stream/event creation failed");
@@ -1515,7 +1519,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.
     const bool wide = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * spt > 2048 || getenv("XPNG_WIDE_RANS"));
     const size_t pad_ch = getenv("XPNG_PAD_CHAIN") ? (size_t)atoi(getenv("XPNG_PAD_CHAIN")) : 0;
-    constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 32;
+    constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 32;  // (16 alpha streams per wave - half the LDS per workgroup, twice the waves - measures the same)
     const uint32_t groups = (total + WD_CTX_STREAMS - 1) / WD_CTX_STREAMS, agroups = (total + WD_ALPHA_STREAMS - 1) / WD_ALPHA_STREAMS;
     if (wide) if (!dbg_skip("dec_prep")) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
     // The alpha branch (its rANS block is the longest serial chain of a tile) and the nl-context branch (nine short
@@ -1558,7 +1562,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const size_t pad_rs = getenv("XPNG_PAD_RS") ? (size_t)atoi(getenv("XPNG_PAD_RS")) : 0;
     if (split) {
         if (!ws.side2) {
-            if (hipStreamCreateWithFlags(&ws.side2, hipStreamNonBlocking) != hipSuccess ||
+            if (chain_stream_create(&ws.side2) != hipSuccess ||
                 hipEventCreateWithFlags(&ws.ev_ctx, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming) != hipSuccess)
                 return bad("stream/event creation failed");

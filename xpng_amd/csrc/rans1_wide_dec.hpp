@@ -303,7 +303,7 @@ inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t t
     k_rans1_dec_prep<<<total * 18, 64, 0, s>>>(d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, ws.d_wdec2, ws.d_dtab2);
     // the two chain launches are independent: the big-alphabet slots run on the side stream beside the small ones
     if (!ws.side) {
-        if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess ||
+        if (chain_stream_create(&ws.side) != hipSuccess ||
             hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess) { err = "stream/event creation failed"; return 1; }
     }

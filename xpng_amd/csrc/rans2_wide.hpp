@@ -111,6 +111,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     __shared__ __align__(16) uint8_t ltab[TPW * TSTRIDE];
     __shared__ __align__(16) uint32_t wbuf[TPW * 32];  // per stream: 16 staged words + 16 nobody reads
     __builtin_amdgcn_s_setprio(3);
+    XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t c = BIG ? 9 : blockIdx.x % 9, grp = BIG ? blockIdx.x : blockIdx.x / 9;
     const uint32_t j = grp * TPW + k;
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     else if (__ballot(live && !cmp) == 0) run(std::true_type{});
     else run(std::false_type{});
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
+    XPNG_PROBE_END(BIG ? 2 : 1)
 }
 
 __global__ __launch_bounds__(64) void k_rans2_finish(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ ctxsym,
                                                         uint8_t *__restrict__ asym) {
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    XPNG_PROBE_BEGIN()
     typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
     constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, WD_RING = L::RING, KIND = BIG ? 2 : 1;
     // LDS copy of a stream's tables: the small layout is searched in registers, so only its fc[] dwords come in (the coarse
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     constexpr uint32_t WD_STREAMS = STREAMS;
     __shared__ __align__(16) uint8_t ltab[WD_STREAMS * TSTRIDE];
     __shared__ __align__(16) uint8_t ring[WD_STREAMS * RSTRIDE];
-    __shared__ __align__(32) uint8_t obuf[WD_STREAMS * 32];     // per stream: 16 symbol bytes of the block + 16 bytes nobody reads
+    __shared__ __align__(32) uint8_t obuf[(WD_STREAMS + 1) * 32];  // per stream: 16 symbol bytes of the block + 16 bytes nobody reads; the last slot belongs to the lanes without a stream (STREAMS < 32)
     const uint32_t lane = threadIdx.x & 63, kraw = lane >> 1, k = kraw < WD_STREAMS ? kraw : 0, par = lane & 1;  // (idle lanes alias stream 0's LDS harmlessly)
     const uint32_t c = c_first + blockIdx.x % c_count, grp = blockIdx.x / c_count;
     const uint32_t j = grp * WD_STREAMS + kraw;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     // LDS byte addresses
     const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + L::CO_OFF;
     const uint32_t a_ring = (uint32_t)(uintptr_t)(lds8 *)ring + k * RSTRIDE + 4;  // word slot i at a_ring + 4 i, the mirror at a_ring - 4
-    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + k * 32;
+    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + (kraw < WD_STREAMS ? kraw : WD_STREAMS) * 32;
     auto ring_w = [&](uint32_t idx) __attribute__((always_inline)) -> lds32 * { return (lds32 *)(uintptr_t)(a_ring + 4 * (idx & (WD_RING - 1))); };
     // ---- initial ring contents: the top 64 words; the states sit right above the words
     uint32_t rw = nw;                               // next word to pop is words[rw - 1]
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             }
         }
     }
+    XPNG_PROBE_END(BIG ? 4 : 3)
 }
 
 }  // namespace xpng

@@ -378,7 +378,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
     const bool alpha_side = !narrow && PXSZ == 4;
     if (alpha_side && !c->enc_side) {
-        HIPCHK(hipStreamCreateWithFlags(&c->enc_side, hipStreamNonBlocking));
+        HIPCHK(chain_stream_create(&c->enc_side));
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
     }
@@ -560,6 +560,22 @@ extern "C" int xpnghip_ctx_decode_status(xpnghip_ctx *c, void *stream) {
 #include "wrappers.hpp"
 
 // ---- introspection for parity tests ----------------------------------------------------------------------
+// wave probe (common.hpp): register a device buffer of `cap` WaveProbe records (nullptr: off); the count so far
+extern "C" int xpnghip_debug_probe(void *d_buf, uint32_t cap) {
+    WaveProbe *p = (WaveProbe *)d_buf;
+    const uint32_t zero = 0;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_buf), &p, sizeof(p)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cap), &cap, sizeof(cap)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_n), &zero, sizeof(zero)));
+    return 0;
+}
+extern "C" int64_t xpnghip_debug_probe_count(void) {
+    uint32_t n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_probe_n), sizeof(n)) != hipSuccess) return -1;
+    return n;
+}
+
 extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, void *out, uint64_t cap) {
     if (!c || tile >= c->tiles.size() || !out) return -1;
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
