@@ -19,6 +19,7 @@ HIP_SYMBOLS = [
     "xpnghip_decode_tiles", "xpnghip_ctx_create", "xpnghip_ctx_destroy", "xpnghip_ctx_tile_count",
     "xpnghip_ctx_tile", "xpnghip_ctx_blob_bound", "xpnghip_ctx_workspace_bytes", "xpnghip_encode_device",
     "xpnghip_ctx_last_blobs_len", "xpnghip_decode_device", "xpnghip_m1_transform_device", "xpnghip_debug_fetch",
+    "xpnghip_debug_probe", "xpnghip_debug_probe_count",
     "xpnghip_ctx_create_batch", "xpnghip_ctx_batch", "xpnghip_encode_device_batch", "xpnghip_ctx_last_blobs_len_at",
     "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range", "xpnghip_ctx_decode_status",
     "xpnghip_image_begin", "xpnghip_image_single_colour", "xpnghip_image_encode", "xpnghip_image_fetch", "xpnghip_image_end",
@@ -106,6 +107,8 @@ def hip_lib():
         L.xpnghip_m1_transform_device_batch.restype = C.c_int
         L.xpnghip_m1_transform_device_batch.argtypes = [vp, C.POINTER(vp), C.c_uint32, u64, u64, vp]
         L.xpnghip_debug_fetch.restype = C.c_int64
+        L.xpnghip_debug_probe.argtypes = [vp, C.c_uint32]
+        L.xpnghip_debug_probe_count.restype = C.c_int64
         L.xpnghip_debug_fetch.argtypes = [vp, C.c_int, u64, vp, u64]
         L.xpnghip_normalize_device.restype = C.c_int
         L.xpnghip_normalize_device.argtypes = [vp, u64, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
