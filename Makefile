@@ -9,12 +9,19 @@ BIN    := xpng_amd/bin
 HIPSRC := $(CSRC)/xpng_hip.hip
 HIPHDR := $(wildcard $(CSRC)/*.hpp) include/xpng_hip.h
 
-all: hip host oracle
+all: hip probes host oracle
 
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -std=c++17 -shared -fPIC -Wall -Wno-unused-function -pthread
 hip: $(LIB)/libxpng_hip.so
 $(LIB)/libxpng_hip.so: $(HIPSRC) $(HIPHDR)
 	@mkdir -p $(LIB)
-	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -shared -fPIC -Wall -Wno-unused-function $(HIPSRC) -o $@
+	$(HIPCC) $(HIPFLAGS) $(HIPSRC) -o $@
+# the same source with the timing-study switches compiled in (kernel knock-outs, LDS pads, stamps, wave probe, fake devices):
+# what tools/ load, never what the product or bench.py loads
+probes: $(LIB)/libxpng_hip_probes.so
+$(LIB)/libxpng_hip_probes.so: $(HIPSRC) $(HIPHDR)
+	@mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -DXPNG_PROBES $(HIPSRC) -o $@
 
 host: $(LIB)/libxpng.so $(BIN)/xpng $(BIN)/seven $(BIN)/tool
 $(LIB)/libxpng.so: $(CSRC)/host/xpng_api.c $(CSRC)/host/seven.c include/xpng.h include/xpng_hip.h $(LIB)/libxpng_hip.so
@@ -36,4 +43,4 @@ oracle:
 clean:
 	rm -rf $(LIB) $(BIN)
 	$(MAKE) -C oracle clean
-.PHONY: all hip host oracle clean
+.PHONY: all hip probes host oracle clean

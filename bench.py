@@ -43,6 +43,24 @@ ALGO_BYTES_PER_PX = {4: 10.0, 3: 7.75}  # read PXSZ + chooser 
 PMC_FILES = {4: "r02_pmc_transform_rgba.json", 3: "r02_pmc_transform_rgb.json"}
 
 
+# Environment hygiene.  The release library reads only same-bytes form selectors; every XPNG_* variable
+# seen is printed in `config.env`.  The timing-study switches (kernel knock-outs, no-store, pads ...) exist only in
+# libxpng_hip_probes.so, which this script loads only under --probe-run (tools/): such a line carries "probe_run": true and is
+# not a benchmark.  Without that flag a skip / no-store switch or the probe library in the environment is refused outright.
+FALSIFYING = ("XPNG_SKIP", "XPNG_SKIP_AFTER", "XPNG_DBG_NOSTORE", "XPNG_USE_PROBES_LIB", "XPNG_FAKE_DEVICES")
+
+
+def env_report(probe_run):
+    seen = {k: v for k, v in sorted(os.environ.items()) if k.startswith("XPNG_")}
+    bad = [k for k in seen if k in FALSIFYING or k.startswith("XPNG_PAD_") or k.startswith("XPNG_DBG_")]
+    if bad and not probe_run:
+        raise SystemExit(f"bench.py: refusing to run with timing-study switches in the environment: {bad} (tools pass --probe-run; such a run is not a benchmark)")
+    if probe_run:
+        os.environ["XPNG_USE_PROBES_LIB"] = "1"
+        seen["XPNG_USE_PROBES_LIB"] = "1"
+    return seen
+
+
 def grid_for(n):
     return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2), 16: (4, 4)}.get(n, (n, 1))
 
@@ -347,7 +365,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="images per launch per rank: a step encodes+decodes `batch` rasters of the workload in one batched launch "
                          "sequence (the entropy stage is a serial chain per tile stream, so one image alone cannot fill 256 CUs)")
+    ap.add_argument("--probe-run", action="store_true", help="tools only: load libxpng_hip_probes.so and accept timing-study switches; the line is marked probe_run and is not a benchmark")
     args = ap.parse_args()
+    env_seen = env_report(args.probe_run)
     if args.level == 2 and not args.rgb:
         raise SystemExit("--level 2 codes RGB only (libxpng.c:755 sends RGBA to level 1): add --rgb")
 
@@ -380,6 +400,8 @@ def main():
                    "--steps", str(max(6, args.steps // 3)), "--warmup", "2", "--roofline-reps", str(max(10, args.roofline_reps // 2)), "--no-legs", "--no-config4"]
             if args.no_cpu:
                 cmd.append("--no-cpu")
+            if args.probe_run:
+                cmd.append("--probe-run")
             try:
                 out_c = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
                 line = [ln for ln in out_c.stdout.splitlines() if ln.startswith("{")][-1]
@@ -409,6 +431,10 @@ def main():
     if rank == 0:
         r = main_res
         ch = r["ch"]
+        from xpng_amd import api as _api
+        lib_name = _api.hip_lib()._name
+        if (_api.hip_lib().xpnghip_probes_built() != 0) != bool(args.probe_run):
+            raise SystemExit("bench.py: the loaded library flavour does not match --probe-run")
         out = {
             "metric": "Mpixels/s encode+decode (bit-exact vs ref)",
             "value": round(r["mpx_s"], 1),
@@ -422,7 +448,7 @@ def main():
                        "batch": B, "pipeline_slots": r["P"], "tiles": r["tiles"], "tiles_per_rank": r["tiles_per_rank"], "share_px": r["my_px"],
                        "parallelism": f"tile-range x{world}" + (f" + file assembly spread over the ranks (image b on rank b % {world}): one packed message per rank pair and step ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
                        "compressed_bytes": r["compressed_bytes"], "distinct_rasters_per_launch": B,
-                       "hbm_in_use_gb": r["hbm_in_use_gb"]},
+                       "hbm_in_use_gb": r["hbm_in_use_gb"], "env": env_seen, "library": os.path.basename(lib_name)},
             "verified": r["verified"],
             "roofline": roofline_obj(r),
             "cpu_baseline": cpu,
@@ -444,6 +470,9 @@ def main():
         out["single_image"] = si
         out["single_image_encode_ms"], out["single_image_decode_ms"] = si["on_device_encode_ms"], si["on_device_decode_ms"]
         out["single_image_encode_mpx_s"], out["single_image_decode_mpx_s"] = si["on_device_encode_mpx_s"], si["on_device_decode_mpx_s"]
+        if args.probe_run:
+            out["probe_run"] = True
+            out["metric"] = "PROBE RUN, not a benchmark: " + out["metric"]
         if legs:
             out["legs"] = legs
         if config4:

@@ -9,6 +9,16 @@
  * failure (the reference's _Bool convention, libxpng.c:729-731); xpnghip_last_error() describes the
  * last failure of the calling thread.  There is NO CPU fallback: without a usable HIP device every
  * compute entry point fails.
+ *
+ * Threading: like the reference (no globals; every call spawns and joins its own workers, until_fork/4_letters.c:9-17) the
+ * host-buffer and staged-image entry points are RE-ENTRANT: any number of host threads may call them at the same time; each
+ * call works on a context, a stream and staging buffers of its own (taken from a pool of idle ones and given back), and no
+ * lock is held while a call runs.  A device-resident context (xpnghip_ctx) is a single-queue object owned by its caller.
+ *
+ * Environment read by the release library (each selects between forms that produce the same bytes):
+ * XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS, XPNG_FUSED, XPNG_UNFUSED, XPNG_SPLIT, XPNG_NO_SPLIT.  Switches that
+ * exist for timing studies (kernel knock-outs, LDS pads, stamps, the wave probe, fake devices) are compiled only into
+ * libxpng_hip_probes.so (`make probes`).
  */
 #ifndef XPNG_HIP_H
 #define XPNG_HIP_H
@@ -19,7 +29,7 @@
 extern "C" {
 #endif
 
-#define XPNGHIP_ABI_VERSION 1
+#define XPNGHIP_ABI_VERSION 2   /* 2: the staged image is a handle (re-entrant xpng_store); T == 0 means one device */
 
 int xpnghip_abi_version(void);
 int xpnghip_device_count(void);          /* visible HIP devices; 0 when none / no runtime */
@@ -40,10 +50,13 @@ int xpnghip_encode_tiles(int mode, const uint8_t *raster, uint64_t w, uint64_t h
 int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h,
                          int pxsz, uint8_t *raster);
 /* The same with the reference's worker count T (libxpng.c:146-151: T workers share the tile cursor, T = min(T, N)).  Here a
- * worker is a DEVICE of this process: T >= 1 uses min(T, visible devices, N) of them, T == 0 (the reference's "auto") as many
- * as leave each at least 256 tiles.  Every device codes one contiguous, pixel-weighted tile range from its own band of the
- * raster; for the encode the blob ranges are gathered on the first device by peer copies (xGMI) for the concatenation of
- * libxpng.c:764-769, then copied to the host once.  The bytes do not depend on T (tiles are coded independently).
+ * worker is a DEVICE of this process: T >= 1 uses min(T, visible devices, N) of them.  T == 0 (the reference's "auto") uses
+ * ONE device: the multi-device path has not yet passed a byte-parity run on real peer devices, so it is opt-in (T > 1, or
+ * XPNG_GPUS=<n> for T == 0).  Every device codes one contiguous, pixel-weighted tile range from its own band of the raster;
+ * for the encode the blob ranges are gathered on the first device by peer copies (xGMI; peer access is queried and enabled
+ * once per device pair) for the concatenation of libxpng.c:764-769, then copied to the host once.  When a pair of devices has
+ * no peer access the copies are staged through host memory by the runtime: the call still succeeds and xpnghip_last_error()
+ * then holds a note that starts with "note:".  The bytes do not depend on T (tiles are coded independently).
  * xpnghip_encode_tiles / xpnghip_decode_tiles are T = 1.  XPNG_DEVICE=<n> selects the first device (default 0); the
  * caller's current HIP device is restored before returning. */
 int xpnghip_encode_tiles_T(uint64_t T, int mode, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz,
@@ -52,6 +65,12 @@ int xpnghip_decode_tiles_T(uint64_t T, int mode, const uint8_t *blobs, uint64_t 
                            int pxsz, uint8_t *raster);
 /* number of devices such a call would use for a w x h image (0 = no usable device) */
 int xpnghip_devices_for(uint64_t T, uint64_t w, uint64_t h);
+/* host-only (needs no device): the contiguous tile ranges a call on D devices would use; ranges[2k], ranges[2k+1] = [r0, r1) of
+ * device k.  Returns the number of ranges (= min(D, tiles)), -1 on bad arguments or cap too small. */
+int xpnghip_shard_ranges(uint64_t w, uint64_t h, int D, uint64_t *ranges, int cap);
+/* Optional: gives every pooled idle object (contexts with their workspaces, staging buffers) back to the runtime.  Must not
+ * run concurrently with other calls into this library. */
+void xpnghip_shutdown(void);
 
 /* ---- staged image: upload once, normalise and test on the device ------------------------------------
  *
@@ -63,18 +82,19 @@ int xpnghip_devices_for(uint64_t T, uint64_t w, uint64_t h);
  *   xpnghip_image_single_colour  <->  the whole-image test of libxpng.c:741-753: *single = 1 if every pixel equals the first.
  *   xpnghip_image_encode         <->  libxpng.c:758-769 on the staged raster (as xpnghip_encode_tiles).
  *   xpnghip_image_fetch               staged raster -> host (w*h*pxsz_out bytes): the level-7 and single-colour outputs.
- *   xpnghip_image_end                 releases the staging lock.
- * One image is staged per process at a time: begin takes a process-wide lock that end releases (begin ... end from
- * several threads serialise); every call between them returns non-zero after a failure, and end must always be called
- * once begin has returned 0.
- * xpnghip_normalize_device is the same rule for a caller whose RGBA raster already lives in HBM: *rewritten = 0 means
- * the raster is already normal (use d_rgba), 1 means d_out (npx * *pxsz_out bytes, caller-allocated npx*4) holds it. */
-int xpnghip_image_begin(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out);
-int xpnghip_image_single_colour(int *single);
-int xpnghip_image_encode(int mode, uint8_t **blobs, uint64_t *blobs_len);
-int xpnghip_image_encode_T(uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len);  /* T devices, as xpnghip_encode_tiles_T */
-int xpnghip_image_fetch(uint8_t *dst);
-void xpnghip_image_end(void);
+ *   xpnghip_image_end                 hands the staging object back (always call it once begin has returned 0).
+ * Every xpng_store call in flight stages its own image: begin returns a handle, the other calls take it.  Handles of different
+ * threads are independent (the reference is re-entrant); one handle is used by one thread at a time.
+ * xpnghip_normalize_device is the same rule for a caller whose RGBA raster already lives in HBM (on the caller's current
+ * device): *rewritten = 0 means the raster is already normal (use d_rgba), 1 means d_out (npx * *pxsz_out bytes,
+ * caller-allocated npx*4) holds it.  It synchronises `stream` once (the two flags come back to the host). */
+typedef struct xpnghip_image xpnghip_image;
+int xpnghip_image_begin(xpnghip_image **img, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out);
+int xpnghip_image_single_colour(xpnghip_image *img, int *single);
+int xpnghip_image_encode(xpnghip_image *img, int mode, uint8_t **blobs, uint64_t *blobs_len);
+int xpnghip_image_encode_T(xpnghip_image *img, uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len);  /* T devices, as xpnghip_encode_tiles_T */
+int xpnghip_image_fetch(xpnghip_image *img, uint8_t *dst);
+void xpnghip_image_end(xpnghip_image *img);
 int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream);
 
 /* ---- device-resident entry points (bench, multi-GPU sharding, pipelines) ---------------------------
@@ -125,7 +145,11 @@ uint64_t xpnghip_ctx_last_blobs_len_at(xpnghip_ctx *ctx, uint32_t img);
  * copies them back to find the offsets.
  * Blob buffers handed to these entry points need 64 readable bytes behind their contents (their last words are fetched in
  * aligned blocks); the host-side wrappers (xpnghip_encode_tiles / xpnghip_decode_tiles / libxpng.so) allocate that
- * themselves.  Rasters need no slack: every kernel that reads one in 16-byte pieces clamps at w*h*pxsz bytes. */
+ * themselves.  A WHOLE raster needs no slack: every kernel that reads one in 16-byte pieces clamps at w*h*pxsz bytes.  A caller
+ * that hands over only a BAND of the raster behind a virtual base pointer (a rank coding tile range [t0, t1) keeps rows
+ * [y0, y1) and passes band - y0*w*pxsz) must keep 16 readable bytes behind the band's last row unless the band ends with the
+ * raster: the clamp is at the end of the whole raster, so the last 16-byte piece of the band's last row may reach up to 15 bytes
+ * into the next row (bench.py and the multi-device wrappers allocate a spare 16 bytes for this). */
 int xpnghip_decode_device(xpnghip_ctx *ctx, int mode, const void *d_blobs, uint64_t blobs_len,
                           const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream);
 
@@ -151,10 +175,12 @@ int xpnghip_m1_transform_device_batch(xpnghip_ctx *ctx, const void *const *d_ras
 int64_t xpnghip_debug_fetch(xpnghip_ctx *ctx, int what, uint64_t tile, void *out, uint64_t cap);
 
 /* ---- wave probe for placement studies (tools/wave_probe.py; no reference counterpart) ---------------
+ * Exists only in libxpng_hip_probes.so (xpnghip_probes_built() == 1); in the release library the two calls fail.
  * Registers a device buffer of `cap` 32-byte records {u32 kernel, block, HW_ID, XCC_ID; u64 t0, t1 (100 MHz)}: wave 0 of every
  * workgroup of the serial-chain kernels appends one when it ends.  d_buf == NULL switches the probe off. */
 int xpnghip_debug_probe(void *d_buf, uint32_t cap);
 int64_t xpnghip_debug_probe_count(void);
+int xpnghip_probes_built(void);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
-    api.build_native(("hip", "host"))
+    api.build_native(("hip", "probes", "host"))
 
 
 def declared(header, prefix):
@@ -33,6 +33,38 @@ def test_hip_library_exports_every_declared_symbol():
     assert not [n for n in names if n not in ex]
 
 
+def test_release_library_has_no_timing_study_switches():
+    """a product .so whose output can be falsified through the environment is not shippable.  The release
+    library may read only the documented same-bytes form selectors; everything else lives in libxpng_hip_probes.so."""
+    allowed = {"XPNG_DEVICE", "XPNG_GPUS", "XPNG_WIDE_RANS", "XPNG_NARROW_RANS", "XPNG_FUSED", "XPNG_UNFUSED", "XPNG_SPLIT",
+               "XPNG_NO_SPLIT"}
+    def names(so):
+        out = subprocess.check_output(["strings", so], text=True)
+        return {ln.strip() for ln in out.splitlines() if re.fullmatch(r"XPNG_[A-Z0-9_]+", ln.strip())}
+    rel, prb = names(api.HIP_SO), names(api.PROBES_SO)
+    assert rel <= allowed, sorted(rel - allowed)
+    assert {"XPNG_SKIP", "XPNG_DBG_NOSTORE", "XPNG_FAKE_DEVICES", "XPNG_STAMPS", "XPNG_PAD_CHAIN"} <= prb
+    ex = exported(api.PROBES_SO)
+    assert not [n for n in api.HIP_SYMBOLS if n not in ex]
+    assert api.hip_lib().xpnghip_probes_built() == 0 and api.probes_lib().xpnghip_probes_built() == 1
+    assert api.hip_lib().xpnghip_debug_probe(None, 0) != 0      # the wave probe does not exist in the release library
+
+
+def test_device_split_matches_the_rank_split():
+    """The C multi-device wrappers (shard_ranges, csrc/wrappers.hpp) and the torch.distributed path (shard.py
+    weighted_tile_ranges) cut an image into the same contiguous pixel-weighted tile ranges; no range is empty while tiles last
+    (an empty shard made a wild host read)."""
+    from xpng_amd.shard import tile_table, weighted_tile_ranges
+    for (w, h) in [(4096, 4096), (16384, 16384), (1500, 1200), (445, 444), (300, 4000), (3799, 1927), (889, 445), (100, 100)]:
+        tiles = tile_table(w, h)
+        for D in (1, 2, 3, 4, 5, 7, 8, 16, 80, 81, 82, 200):
+            got = api.shard_ranges(w, h, D)
+            want = [r for r in weighted_tile_ranges(tiles, D) if r[0] < r[1] or len(tiles) == 0]
+            assert got == want, (w, h, D)
+            assert len(got) == min(D, len(tiles)) and got[0][0] == 0 and got[-1][1] == len(tiles)
+            assert all(a < b for a, b in got) and all(x[1] == y[0] for x, y in zip(got, got[1:]))
+
+
 def test_host_library_exports_reference_api():
     names = [n for n in declared("xpng.h", "xpng_") if n != "xpng_t"] + ["store_7", "load_7"]
     assert sorted(names) == sorted(api.HOST_SYMBOLS)
@@ -42,7 +74,7 @@ def test_host_library_exports_reference_api():
 
 def test_libraries_load_and_report_no_device_without_gpu():
     L = api.hip_lib()
-    assert L.xpnghip_abi_version() == 1
+    assert L.xpnghip_abi_version() == 2
     assert L.xpnghip_device_count() >= 0
     api.host_lib()
 

@@ -586,29 +586,162 @@ def test_device_side_size_walk(gpu, po):
 def test_worker_count_T_shards_tile_ranges_over_devices(gpu, po, tmp_path, monkeypatch, T):
     """xpng_store_T / xpng_load_T with T > 1 (reference libxpng.c:146-151: T workers over the tile cursor): T devices of one
     process each code a contiguous pixel-weighted tile range from their own band of the raster; blob ranges are gathered on
-    the first device (peer copies) for the concatenation.  On this one-GPU box the T shards are rehearsed on one device
-    (XPNG_FAKE_DEVICES); the bytes must not depend on T.  Odd widths: band starts at every 16-byte phase."""
+    the first device (peer copies) for the concatenation.  On a one-GPU box the T shards are rehearsed on one device: that
+    switch (XPNG_FAKE_DEVICES) exists only in the PROBES build of the library, which this test loads beside the release one.
+    The bytes must not depend on T.  Odd widths: band starts at every 16-byte phase."""
     from xpng_amd import api
     from xpng_amd.synth import synth_raster
+    P = api.probes_lib()
     monkeypatch.setenv("XPNG_FAKE_DEVICES", str(T))
-    assert api.hip_lib().xpnghip_devices_for(T, 1501, 1203) == T
-    assert api.hip_lib().xpnghip_devices_for(0, 1501, 1203) == 1          # automatic: one device below 256 tiles each
+    assert P.xpnghip_devices_for(T, 1501, 1203) == T
+    assert P.xpnghip_devices_for(0, 1501, 1203) == 1          # automatic = ONE device (multi-device is opt-in)
+    assert P.xpnghip_devices_for(0, 16384, 16384) == 1
+    assert api.hip_lib().xpnghip_devices_for(T, 1501, 1203) == min(T, api.device_count())   # the release library ignores the switch
     for (W, H, alpha, level) in [(1500, 1200, True, 1), (1501, 1203, False, 1), (1501, 1203, False, 2), (1499, 1300, True, 1)]:
         raster = synth_raster("photo", W, H, alpha, seed=7)
         want = po.encode_image(level, raster)
         p = tmp_path / "t.xpng"
-        gpu.store(level, raster, str(p), T=T)
+        gpu.store(level, raster, str(p), T=T)                  # release library: min(T, real devices) devices
         assert p.read_bytes() == want, (W, H, alpha, level)
         assert np.array_equal(gpu.load(str(p), T=T), raster), (W, H, alpha, level)
-        blobs = api.encode_tiles(level, raster, T=T)
+        blobs = api.encode_tiles(level, raster, T=T, lib=P)    # T shards (host raster -> bands)
         assert blobs == want[8:]
-        assert np.array_equal(api.decode_tiles(level, blobs, W, H, raster.shape[2], T=T), raster)
+        assert np.array_equal(api.decode_tiles(level, blobs, W, H, raster.shape[2], T=T, lib=P), raster)
+        pxsz, single, blobs2, norm = api.staged_encode(level, raster, T=T, lib=P)   # T shards from the staged device raster (xpng_store's path)
+        assert (pxsz, single, blobs2) == (raster.shape[2], False, want[8:]) and norm == raster.tobytes()
     # corrupt file on the multi-device path: rejected, not executed
-    bad = bytearray(want)
-    bad[12:16] = b"\xff\xff\xff\x7f"                                  # k size of tile 0 beyond its blob
-    p.write_bytes(bytes(bad))
-    with pytest.raises(gpu.XpngError):
-        gpu.load(str(p), T=T)
+    bad = bytearray(want[8:])
+    bad[4:8] = b"\xff\xff\xff\x7f"                                  # k size of tile 0 beyond its blob
+    with pytest.raises(api.XpngError):
+        api.decode_tiles(level, bytes(bad), W, H, raster.shape[2], T=T, lib=P)
+
+
+def test_two_real_devices_code_the_same_bytes(gpu, po):
+    """Hardware-gated: with two or more REAL devices xpnghip_encode_tiles_T(T=2) / decode must give the oracle's
+    bytes through peer copies.  Skipped on one-GPU boxes - which is every box this suite has run on so far."""
+    from xpng_amd import api
+    from xpng_amd.synth import synth_raster
+    if api.device_count() < 2:
+        pytest.skip("one visible device: the multi-device C path has still never run on real peers")
+    for (W, H, alpha, level) in [(1501, 1203, True, 1), (1501, 1203, False, 2)]:
+        raster = synth_raster("photo", W, H, alpha, seed=3)
+        want = po.encode_image(level, raster)[8:]
+        assert api.encode_tiles(level, raster, T=2) == want
+        assert np.array_equal(api.decode_tiles(level, want, W, H, raster.shape[2], T=2), raster)
+
+
+def test_concurrent_store_and_load_from_two_host_threads(gpu, manifest, tmp_path):
+    """The reference is re-entrant (no globals; every call spawns its own workers: until_fork/4_letters.c:9-17, SURVEY 8(b)
+    "Threading").  Two host threads call xpng_store / xpng_load at the same time on different images (ctypes releases the
+    GIL): every output must equal the reference's golden bytes, and nothing may dead-lock or serialise on a lock held across
+    calls (the staged image is a per-call handle, contexts are checked out of a pool)."""
+    import threading
+    from xpng_amd.synth import to_seven_bytes
+    ents = [(n, e) for n, e in small_entries(manifest) if "L1" in e and "L2" in e][:14]
+    assert len(ents) >= 8
+    jobs = [(n, e, golden_raster(n, e)) for n, e in ents]
+    errors = []
+
+    def worker(k):
+        try:
+            order = jobs if k == 0 else jobs[::-1]             # both threads visit every image, from opposite ends
+            for rep in range(2):
+                for i, (n, e, raster) in enumerate(order):
+                    for level in (1, 2):
+                        g = e.get(f"L{level}")
+                        if g is None:
+                            continue
+                        out = tmp_path / f"t{k}_{i}_{level}.xpng"
+                        gpu.store(level, raster, str(out))
+                        data = out.read_bytes()
+                        if md5(data) != g["md5"]:
+                            errors.append((k, n, level, "store"))
+                        back = gpu.load(str(out))
+                        if md5(to_seven_bytes(back)) != g["decoded_md5"]:
+                            errors.append((k, n, level, "load"))
+        except Exception as ex:   # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in ths), "a thread is stuck"
+    assert not errors, errors[:5]
+
+
+def test_concurrent_calls_really_overlap(gpu):
+    """Two threads inside xpnghip_encode_tiles at the same time both finish, with the same bytes as a serial call, and the pair
+    takes less than twice a single call (no lock is held across a call).  Timing assertion is loose: it only has to
+    distinguish "serialised" from "side by side"."""
+    import threading
+    import time
+    from xpng_amd import api
+    from xpng_amd.synth import synth_raster
+    rasters = [synth_raster("photo", 2048, 2048, True, seed=s) for s in (11, 12)]
+    want = [api.encode_tiles(1, r) for r in rasters]
+    api.encode_tiles(1, rasters[0]); api.encode_tiles(1, rasters[1])          # warm: contexts exist
+    t0 = time.perf_counter()
+    for r in rasters:
+        api.encode_tiles(1, r)
+    serial = time.perf_counter() - t0
+    got = [None, None]
+
+    def run(k):
+        got[k] = api.encode_tiles(1, rasters[k])
+    best = 1e9
+    for _ in range(3):
+        ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        best = min(best, time.perf_counter() - t0)
+        assert got == want
+    print(f"two encodes: serial {serial * 1e3:.1f} ms, concurrent {best * 1e3:.1f} ms")
+    assert best < serial * 1.05
+
+
+def test_first_call_on_a_fresh_context_may_be_anything(gpu, po):
+    """Regression for the abort of gpurun_out/r2_t14.log: a context's lazily allocated buffers (the five
+    symbol planes, the mode-2 workspace) are allocated by whichever launch sequence needs them first - a mode-2 encode, the
+    transform-only entry, a fused or unfused mode-1 encode - and a launch never hands a null workspace pointer to a kernel
+    (that is a GPU fault, i.e. abort(), not an error return)."""
+    import torch
+    import xpng_amd
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import synth_raster
+    raster = synth_raster("photo", 700, 500, False, seed=5)
+    h, w, ch = raster.shape
+    d_r = torch.from_numpy(raster).cuda()
+    for first in ("m2_encode", "transform", "m2_decode", "m1_encode", "fetch"):
+        ctx = xpng_amd.Context(w, h, ch)
+        d_b = torch.zeros(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        if first == "m2_encode":
+            n = ctx.encode_device(2, d_r.data_ptr(), d_b.data_ptr())
+            assert d_b[:n].cpu().numpy().tobytes() == po.encode_tiles(2, raster)
+        elif first == "transform":
+            ctx.transform_device(d_r.data_ptr())
+            t0_ = ctx.tiles()[0]
+            pr, _ = po.choose_predictor(raster, t0_)
+            assert np.array_equal(ctx.fetch("nl", 0), po.m1_planes(raster, t0_, pr)["nl"])
+        elif first == "m2_decode":
+            blobs = po.encode_tiles(2, raster)
+            d_b[: len(blobs)] = torch.frombuffer(bytearray(blobs), dtype=torch.uint8).cuda()
+            off, _ = walk_tile_offsets(blobs, ctx.n_tiles)
+            d_o = torch.zeros(h * w * ch + 64, dtype=torch.uint8, device="cuda")
+            ctx.decode_device(2, d_b.data_ptr(), len(blobs), off, d_o.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_o[: h * w * ch].cpu().numpy().reshape(h, w, ch), raster)
+        elif first == "m1_encode":
+            n = ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
+            assert d_b[:n].cpu().numpy().tobytes() == po.encode_tiles(1, raster)
+        else:
+            with pytest.raises(xpng_amd.api.XpngError):
+                ctx.fetch("nl", 0)                               # planes that do not exist yet: an error, not a null read
+        ctx.close()
 
 
 @pytest.mark.parametrize("force_wide", [False, True])

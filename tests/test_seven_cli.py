@@ -51,3 +51,28 @@ def test_to_7_normalises_like_xpng_store(tmp_path):
         got = load_seven(str(out))
         want = np.ascontiguousarray(po.normalize_rgba(r))
         assert got.shape == want.shape and np.array_equal(got, want), case
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/images"), reason="reference corpus not present (container-only test)")
+def test_to_7_on_the_reference_corpus_gives_the_pinned_md5s():
+    """SURVEY 8(c) / DESIGN 8: `seven --to_7` (host/seven_cli.c, the libpng16 runtime bound by dlopen) on the reference's own
+    images/*.png (test.rb:28-30 feeds exactly these) produces the .7 files whose md5 the manifest pins as `seven_md5` - the
+    inputs every corpus golden was generated from (reference 7/seven.c:39-79)."""
+    import hashlib
+    import json
+    import tempfile
+    from conftest import GOLD, corpus_entries
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))
+    checked = 0
+    with tempfile.TemporaryDirectory() as td:
+        for name, ent in corpus_entries(man):
+            stem = name.split("_", 1)[1]
+            png = os.path.join("/root/reference/images", stem + ".png")
+            assert os.path.exists(png), png
+            out = os.path.join(td, "o.7")
+            assert subprocess.run([SEVEN, "--to_7", png, out]).returncode == 0
+            data = open(out, "rb").read()
+            assert hashlib.md5(data).hexdigest() == ent["seven_md5"], stem
+            assert len(data) == 8 + ent["w"] * ent["h"] * ent["ch"]
+            checked += 1
+    assert checked == 17

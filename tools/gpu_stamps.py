@@ -3,6 +3,7 @@
 import os, sys
 import numpy as np
 os.environ["XPNG_STAMPS"] = "1"
+os.environ["XPNG_USE_PROBES_LIB"] = "1"  # the switches this tool uses exist only in libxpng_hip_probes.so (make probes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -19,6 +19,7 @@ GROUPS = {"enc_chains": "chain_a,chain_c", "dec_chains": "dec_chain_a,dec_chain_
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     P, B, mode = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+    os.environ["XPNG_USE_PROBES_LIB"] = "1"  # the switches this tool uses exist only in libxpng_hip_probes.so (make probes)
     sys.path.insert(0, ROOT)
     import torch
     import xpng_amd

@@ -5,6 +5,7 @@ csrc/common.hpp), runs P slots x B rasters of encode+decode steps, and for every
 duration against that co-residency.   usage: wave_probe.py [P=4] [B=64] [steps=12]"""
 import ctypes, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ["XPNG_USE_PROBES_LIB"] = "1"  # the switches this tool uses exist only in libxpng_hip_probes.so (make probes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "xpng_amd", "lib")
 HIP_SO = os.path.join(LIBDIR, "libxpng_hip.so")
+PROBES_SO = os.path.join(LIBDIR, "libxpng_hip_probes.so")  # -DXPNG_PROBES build: timing-study switches, wave probe, fake devices
 HOST_SO = os.path.join(LIBDIR, "libxpng.so")
 CLI = os.path.join(ROOT, "xpng_amd", "bin", "xpng")
 
@@ -24,6 +25,7 @@ HIP_SYMBOLS = [
     "xpnghip_decode_device_batch", "xpnghip_m1_transform_device_batch", "xpnghip_ctx_create_range", "xpnghip_ctx_decode_status",
     "xpnghip_image_begin", "xpnghip_image_single_colour", "xpnghip_image_encode", "xpnghip_image_fetch", "xpnghip_image_end",
     "xpnghip_normalize_device", "xpnghip_encode_tiles_T", "xpnghip_decode_tiles_T", "xpnghip_image_encode_T", "xpnghip_devices_for",
+    "xpnghip_shard_ranges", "xpnghip_shutdown", "xpnghip_probes_built",
 ]
 HOST_SYMBOLS = ["xpng_store", "xpng_load", "xpng_from_jpg", "xpng_store_T", "xpng_load_T", "xpng_from_jpg_T",
                 "store_7", "load_7"]
@@ -48,14 +50,12 @@ class XpngT(C.Structure):  # include/xpng.h xpng_t
 
 _hip = None
 _host = None
+_probes = None
 
 
-def hip_lib():
-    global _hip
-    if _hip is None:
-        if not os.path.exists(HIP_SO):
-            raise XpngError(f"{HIP_SO} is missing: run `make hip` (there is no CPU fallback)")
-        L = C.CDLL(HIP_SO)
+def _bind_hip(path):
+    L = C.CDLL(path)
+    if True:
         u64, vp = C.c_uint64, C.c_void_p
         L.xpnghip_abi_version.restype = C.c_int
         L.xpnghip_device_count.restype = C.c_int
@@ -112,8 +112,52 @@ def hip_lib():
         L.xpnghip_debug_fetch.argtypes = [vp, C.c_int, u64, vp, u64]
         L.xpnghip_normalize_device.restype = C.c_int
         L.xpnghip_normalize_device.argtypes = [vp, u64, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
-        _hip = L
+        L.xpnghip_shard_ranges.restype = C.c_int
+        L.xpnghip_shard_ranges.argtypes = [u64, u64, C.c_int, C.POINTER(u64), C.c_int]
+        L.xpnghip_shutdown.restype = None
+        L.xpnghip_probes_built.restype = C.c_int
+        L.xpnghip_image_begin.restype = C.c_int
+        L.xpnghip_image_begin.argtypes = [C.POINTER(vp), vp, u64, u64, C.c_int, C.POINTER(C.c_int)]
+        L.xpnghip_image_single_colour.restype = C.c_int
+        L.xpnghip_image_single_colour.argtypes = [vp, C.POINTER(C.c_int)]
+        L.xpnghip_image_encode_T.restype = C.c_int
+        L.xpnghip_image_encode_T.argtypes = [vp, u64, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
+        L.xpnghip_image_fetch.restype = C.c_int
+        L.xpnghip_image_fetch.argtypes = [vp, vp]
+        L.xpnghip_image_end.restype = None
+        L.xpnghip_image_end.argtypes = [vp]
+    return L
+
+
+def hip_lib():
+    """The release library.  XPNG_USE_PROBES_LIB=1 (tools/ only) makes every binding in this module use the probe build."""
+    global _hip
+    if _hip is None:
+        path = PROBES_SO if os.environ.get("XPNG_USE_PROBES_LIB") else HIP_SO
+        if not os.path.exists(path):
+            raise XpngError(f"{path} is missing: run `make hip` (there is no CPU fallback)")
+        _hip = _bind_hip(path)
     return _hip
+
+
+def probes_lib():
+    """libxpng_hip_probes.so (-DXPNG_PROBES) as a second, independent handle: for the tests / tools that need a switch the
+    release library does not have (XPNG_FAKE_DEVICES, XPNG_SKIP, pads, the wave probe)."""
+    global _probes
+    if _probes is None:
+        if not os.path.exists(PROBES_SO):
+            raise XpngError(f"{PROBES_SO} is missing: run `make probes`")
+        _probes = _bind_hip(PROBES_SO)
+    return _probes
+
+
+def shard_ranges(w: int, h: int, D: int):
+    """Tile ranges a host-buffer call on D devices uses (xpnghip_shard_ranges; host-only, needs no GPU)."""
+    arr = (C.c_uint64 * (2 * max(D, 1)))()
+    n = hip_lib().xpnghip_shard_ranges(w, h, D, arr, max(D, 1))
+    if n < 0:
+        raise XpngError("xpnghip_shard_ranges failed")
+    return [(int(arr[2 * k]), int(arr[2 * k + 1])) for k in range(n)]
 
 
 def host_lib():
@@ -147,25 +191,53 @@ _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
 
 
-def encode_tiles(mode: int, raster: np.ndarray, T: int = 1) -> bytes:
+def encode_tiles(mode: int, raster: np.ndarray, T: int = 1, lib=None) -> bytes:
     """Host raster (h, w, 3|4) uint8 -> concatenated tile blobs (xpnghip_encode_tiles_T; H2D + kernels + D2H) on T devices."""
     raster = np.ascontiguousarray(raster, dtype=np.uint8)
     h, w, ch = raster.shape
     p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
-    if hip_lib().xpnghip_encode_tiles_T(T, mode, raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(p), C.byref(n)):
-        raise XpngError("xpnghip_encode_tiles: " + _err())
+    lib = lib or hip_lib()
+    if lib.xpnghip_encode_tiles_T(T, mode, raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(p), C.byref(n)):
+        raise XpngError("xpnghip_encode_tiles: " + lib.xpnghip_last_error().decode(errors="replace"))
     out = C.string_at(p, n.value)
     _libc.free(p)
     return out
 
 
-def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int, T: int = 1) -> np.ndarray:
+def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int, T: int = 1, lib=None) -> np.ndarray:
     raster = np.zeros((h, w, pxsz), dtype=np.uint8)
     buf = np.frombuffer(blobs, dtype=np.uint8)
-    if hip_lib().xpnghip_decode_tiles_T(T, mode, buf.ctypes.data_as(C.c_void_p), len(blobs), w, h, pxsz,
-                                        raster.ctypes.data_as(C.c_void_p)):
-        raise XpngError("xpnghip_decode_tiles: " + _err())
+    lib = lib or hip_lib()
+    if lib.xpnghip_decode_tiles_T(T, mode, buf.ctypes.data_as(C.c_void_p), len(blobs), w, h, pxsz,
+                                  raster.ctypes.data_as(C.c_void_p)):
+        raise XpngError("xpnghip_decode_tiles: " + lib.xpnghip_last_error().decode(errors="replace"))
     return raster
+
+
+def staged_encode(mode: int, raster: np.ndarray, T: int = 1, lib=None):
+    """The staged-image sequence xpng_store runs (xpnghip_image_begin .. _end): returns (bytes per pixel after
+    normalize_RGBA, single-colour?, tile blobs, normalised raster bytes)."""
+    raster = np.ascontiguousarray(raster, dtype=np.uint8)
+    h, w, ch = raster.shape
+    lib = lib or hip_lib()
+    img, pxsz = C.c_void_p(), C.c_int(0)
+    if lib.xpnghip_image_begin(C.byref(img), raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(pxsz)):
+        raise XpngError("xpnghip_image_begin: " + lib.xpnghip_last_error().decode(errors="replace"))
+    try:
+        single = C.c_int(0)
+        if lib.xpnghip_image_single_colour(img, C.byref(single)):
+            raise XpngError("xpnghip_image_single_colour: " + lib.xpnghip_last_error().decode(errors="replace"))
+        norm = np.zeros(h * w * pxsz.value, dtype=np.uint8)
+        if lib.xpnghip_image_fetch(img, norm.ctypes.data_as(C.c_void_p)):
+            raise XpngError("xpnghip_image_fetch: " + lib.xpnghip_last_error().decode(errors="replace"))
+        p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+        if lib.xpnghip_image_encode_T(img, T, mode, C.byref(p), C.byref(n)):
+            raise XpngError("xpnghip_image_encode_T: " + lib.xpnghip_last_error().decode(errors="replace"))
+        blobs = C.string_at(p, n.value)
+        _libc.free(p)
+        return pxsz.value, bool(single.value), blobs, norm.tobytes()
+    finally:
+        lib.xpnghip_image_end(img)
 
 
 def store(mode: int, raster: np.ndarray, path: str, T: int = None) -> None:

@@ -9,18 +9,36 @@
 
 namespace xpng {
 
+// ---- build flavours ---------------------------------------------------------------------------------------------------
+// The release library (libxpng_hip.so) reads exactly these environment variables, each of which selects between forms that
+// produce the SAME bytes (INTEGRATION.md lists them): XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS, XPNG_FUSED,
+// XPNG_UNFUSED, XPNG_SPLIT, XPNG_NO_SPLIT (and the runtime's own GPU_MAX_HW_QUEUES).  Everything that exists for timing
+// studies - kernel knock-outs, unused-LDS pads, no-store switches, phase stamps, the wave probe, stream priorities, fake
+// devices - is compiled only into libxpng_hip_probes.so (-DXPNG_PROBES, `make probes`; tools/ load that one): a product
+// library whose output can be falsified through the environment is not shippable.
+#ifdef XPNG_PROBES
+inline const char *probe_env(const char *name) { return getenv(name); }
+#else
+inline const char *probe_env(const char *) { return nullptr; }
+#endif
+inline size_t probe_pad(const char *name) { const char *v = probe_env(name); return v ? (size_t)atoi(v) : 0; }  // bytes of unused dynamic LDS (occupancy throttle)
+
 // Streams that carry serial-chain kernels.  tools/wave_probe.py shows that in the pipelined bench the chain WAVES run at their solo
 // speed while the chain KERNELS take 1.7x longer: their workgroups (tens of KB of LDS each) trickle onto CUs that bandwidth kernels
-// with 10^4..10^5 queued workgroups keep full.  Stream priority is the obvious lever and the wrong one:
+// with 10^4..10^5 queued workgroups keep full.  Stream priority is the obvious lever and the wrong one (measured: 27.8 against
+// 39.2 Gpx/s with the highest priority - the normal-priority queues starve while a priority kernel runs), so the priority is 0
+// outside probe builds.
 inline hipError_t chain_stream_create(hipStream_t *s) {
-    static const int prio = [] { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); return getenv("XPNG_STREAM_PRIORITY") ? hi : 0; }();  // (measured: 27.8 against 39.2 Gpx/s with the highest priority - the normal-priority queues starve while a priority kernel runs - so the default is 0)
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+    int lo = 0, hi = 0;
+    if (probe_env("XPNG_STREAM_PRIORITY")) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, probe_env("XPNG_STREAM_PRIORITY") ? hi : 0);
 }
 
-// Wave probe for placement studies (tools/wave_probe.py): when a buffer is registered (xpnghip_debug_probe), wave 0 of every
-// workgroup of the serial-chain kernels records where it ran (HW_ID: SE / CU / SIMD / wave slot; XCC_ID) and when (constant
-// 100 MHz clock).  One scalar load and a not-taken branch per kernel when no buffer is registered.
+// Wave probe for placement studies (tools/wave_probe.py; probe builds only): when a buffer is registered (xpnghip_debug_probe),
+// wave 0 of every workgroup of the serial-chain kernels records where it ran (HW_ID: SE / CU / SIMD / wave slot; XCC_ID) and
+// when (constant 100 MHz clock).
 struct WaveProbe { uint32_t kernel, block, hwid, xcc; uint64_t t0, t1; };
+#ifdef XPNG_PROBES
 __device__ WaveProbe *g_probe_buf = nullptr;
 __device__ uint32_t g_probe_cap = 0, g_probe_n = 0;
 #define XPNG_PROBE_BEGIN()                                                                        \
@@ -34,11 +52,17 @@ __device__ uint32_t g_probe_cap = 0, g_probe_n = 0;
             probe_buf_[pi_] = WaveProbe{(uint32_t)(kid), blockIdx.x, (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4),     \
                                         (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20), probe_t0_, __builtin_amdgcn_s_memrealtime()}; \
     }
+#else
+#define XPNG_PROBE_BEGIN()
+#define XPNG_PROBE_END(kid)
+#endif
 
-// Knock-out switch for timing studies (tools/knockout.py): XPNG_SKIP=name,name,... leaves the named kernels of the batched
-// level-1 paths unlaunched once XPNG_SKIP_AFTER launch sequences have run complete (the workspaces then still hold the
-// previous, identical results, so everything downstream keeps working on valid data).  Never set in production.
+// Knock-out switch for timing studies (tools/knockout.py; probe builds only): XPNG_SKIP=name,name,... leaves the named kernels
+// of the batched level-1 paths unlaunched once XPNG_SKIP_AFTER launch sequences have run complete (the workspaces then still
+// hold the previous, identical results, so everything downstream keeps working on valid data).
+#ifdef XPNG_PROBES
 inline std::atomic<uint64_t> &dbg_sequences() { static std::atomic<uint64_t> n{0}; return n; }  // (callers may come from several host threads)
+inline void dbg_count_sequence() { dbg_sequences().fetch_add(1, std::memory_order_relaxed); }
 inline bool dbg_skip(const char *name) {
     static const char *list = getenv("XPNG_SKIP");
     if (!list) return false;
@@ -49,6 +73,10 @@ inline bool dbg_skip(const char *name) {
         if ((p == list || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
     return false;
 }
+#else
+inline void dbg_count_sequence() {}
+constexpr bool dbg_skip(const char *) { return false; }
+#endif
 
 constexpr uint32_t TILE_AREA = 444u * 444u;  // reference libxpng.c:49
 constexpr uint32_t NL_NONE = 0xFFu;          // nl-plane marker: pixel emits no colour symbol

@@ -81,7 +81,8 @@ static void print_rate(const char *what, uint64_t workers, uint64_t ns, uint64_t
  * device.  The normalised raster comes back to the host only for the outputs that contain it verbatim. */
 static _Bool store_on_device(uint64_t T, uint64_t mode, const xpng_t *pm, const char *fn, uint64_t t_start) {
     int pxsz = 0;
-    if (xpnghip_image_begin(pm->p, pm->w, pm->h, 3 + pm->A, &pxsz)) {
+    xpnghip_image *img = NULL; /* this call's own staging object: concurrent xpng_store calls do not share state */
+    if (xpnghip_image_begin(&img, pm->p, pm->w, pm->h, 3 + pm->A, &pxsz)) {
         fprintf(stderr, "xpng: GPU staging failed: %s\n", xpnghip_last_error());
         return 1;
     }
@@ -94,9 +95,9 @@ static _Bool store_on_device(uint64_t T, uint64_t mode, const xpng_t *pm, const 
     put_u32(hdr + 4, (uint32_t)(pm->h - 1) | ((uint32_t)A << 24));
     if (mode == 2) { /* libxpng.c:741-753 */
         int single = 0;
-        if (xpnghip_image_single_colour(&single)) goto done;
+        if (xpnghip_image_single_colour(img, &single)) goto done;
         if (single) {
-            if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
+            if (!(raw = malloc(s)) || xpnghip_image_fetch(img, raw)) goto done;
             hdr[7] |= 2;
             rc = write_file(fn, hdr, raw, (uint64_t)pxsz);
             goto done;
@@ -104,27 +105,27 @@ static _Bool store_on_device(uint64_t T, uint64_t mode, const xpng_t *pm, const 
     }
     if (A && mode == 2) { mode = 1; hdr[3] = 1; } /* libxpng.c:755 */
     if (A && (pm->w < 4 || pm->h < 4)) { /* reference behaviour undefined here: store uncompressed */
-        if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
+        if (!(raw = malloc(s)) || xpnghip_image_fetch(img, raw)) goto done;
         hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
         rc = write_file(fn, hdr, raw, s);
         goto done;
     }
     {
         uint64_t blen = 0;
-        if (xpnghip_image_encode_T(T, (int)mode, &blobs, &blen)) {
+        if (xpnghip_image_encode_T(img, T, (int)mode, &blobs, &blen)) {
             fprintf(stderr, "xpng: GPU tile encode failed: %s\n", xpnghip_last_error());
             goto done;
         }
         /* the reference prints its worker-thread count here (libxpng.c:761); the workers of this library are GPUs */
         print_rate("encode", (uint64_t)xpnghip_devices_for(T, pm->w, pm->h), now_ns() - t_start, pm->w * pm->h);
         if (blen >= s) { /* libxpng.c:771-777 */
-            if (!(raw = malloc(s)) || xpnghip_image_fetch(raw)) goto done;
+            if (!(raw = malloc(s)) || xpnghip_image_fetch(img, raw)) goto done;
             hdr[3] = XPNG_COMPRESSION_TYPE_UNCOMPRESSED;
             rc = write_file(fn, hdr, raw, s);
         } else rc = write_file(fn, hdr, blobs, blen);
     }
 done:
-    xpnghip_image_end();
+    xpnghip_image_end(img);
     free(raw);
     free(blobs);
     return rc;

@@ -1448,7 +1448,7 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
         //  of a tile's steps, i.e. read up to a tile's pixel count past that queue's start)
         const uint64_t sz[5] = {rup(plane + 8192 + 450000, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(plane + 64, 256), rup(4 * plane + 1024, 256)};
         void *pl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        if (ws.arena && ws.arena_bytes >= sz[0] + sz[1] + sz[2] + sz[3] + sz[4] + 256 && !getenv("XPNG_NO_ARENA")) {
+        if (ws.arena && ws.arena_bytes >= sz[0] + sz[1] + sz[2] + sz[3] + sz[4] + 256 && !probe_env("XPNG_NO_ARENA")) {
             uint8_t *q = reinterpret_cast<uint8_t *>(rup(reinterpret_cast<uintptr_t>(ws.arena), 256));
             for (int i = 0; i < 5; i++) { pl[i] = q; q += sz[i]; }
             ws.planes_in_arena = true;
@@ -1490,7 +1490,7 @@ inline int decode_ws_prepare(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_
 inline void recon_geometry(uint32_t max_w, uint32_t max_h, uint32_t &free_ew, uint32_t &threads, uint32_t &lds) {
     const uint32_t nw = (max_h + 63) / 64;
     free_ew = 0; threads = 1024; lds = 0;
-    if (getenv("XPNG_BARRIER_RECON") || max_h > 1024 || (uint64_t)nw * max_w * 4 + 64 > 60000) return;
+    if (probe_env("XPNG_BARRIER_RECON") || max_h > 1024 || (uint64_t)nw * max_w * 4 + 64 > 60000) return;
     free_ew = max_w; threads = nw * 64; lds = nw * max_w * 4 + 64;
 }
 
@@ -1503,8 +1503,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
-    dbg_sequences().fetch_add(1, std::memory_order_relaxed);
+    dbg_count_sequence();
     if (decode_ws_prepare(ws, B, n_tiles, plane, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
+    // (a null workspace pointer handed to a kernel is a GPU fault, i.e. abort(): refuse to launch instead)
+    if (!ws.d_info || !ws.d_off || !ws.d_wdec || !ws.d_dtab || !ws.d_ctxsym || !ws.d_asym || !ws.d_alpha || !ws.d_nlseq || !ws.d_resid || !d_tiles || !d_blob_ptrs || !d_raster_ptrs)
+        return bad("internal error: a decode workspace buffer was never allocated");
     const uint64_t bpr = W * (uint64_t)pxsz;
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
@@ -1518,7 +1521,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // Many tiles in flight: instruction issue is the bound, so the rANS chains run 32 streams to a wave (rans2_wide_dec.hpp);
     // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.
     const bool wide = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * spt > 2048 || getenv("XPNG_WIDE_RANS"));
-    const size_t pad_ch = getenv("XPNG_PAD_CHAIN") ? (size_t)atoi(getenv("XPNG_PAD_CHAIN")) : 0;
+    const size_t pad_ch = probe_pad("XPNG_PAD_CHAIN");
     constexpr uint32_t WD_CTX_STREAMS = 32, WD_ALPHA_STREAMS = 32;  // (16 alpha streams per wave - half the LDS per workgroup, twice the waves - measures the same)
     const uint32_t groups = (total + WD_CTX_STREAMS - 1) / WD_CTX_STREAMS, agroups = (total + WD_ALPHA_STREAMS - 1) / WD_ALPHA_STREAMS;
     if (wide) if (!dbg_skip("dec_prep")) k_rans2_dec_prep<<<total * spt, 64, 0, s>>>(ws.d_info, d_tiles, sel, spt, ws.d_ctxsym, ws.d_asym, ws.d_wdec, ws.d_dtab);
@@ -1526,9 +1529,9 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
-        if (wide && !getenv("XPNG_NARROW_ALPHA")) { if (!dbg_skip("dec_chain_a")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, pad_ch, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym); }
+        if (wide && !probe_env("XPNG_NARROW_ALPHA")) { if (!dbg_skip("dec_chain_a")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, pad_ch, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym); }
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
-        const size_t pad_al = getenv("XPNG_PAD_AL") ? (size_t)atoi(getenv("XPNG_PAD_AL")) : 0;
+        const size_t pad_al = probe_pad("XPNG_PAD_AL");
         if (dbg_skip("dec_alpha")) {} else if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
@@ -1545,21 +1548,21 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // first n_big tiles of the order (x B images) are walked on `s` while the rest - shorter chains - are walked on a second
     // stream, which then extracts residuals and reconstructs them while the big walk is still running; what is left behind
     // the long walk is the residual / reconstruction work of the few big tiles only.
-    const bool band = wide && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON");
+    const bool band = wide && max_w <= RB_MAXW && !probe_env("XPNG_WAVEFRONT_RECON");
     // (a third stream per context: with fewer hardware queues than the streams of all contexts in flight, streams share a queue
     // and serialise - measured 31 -> 21 Gpx/s at 4 contexts and 16 queues - so the split is taken only when the process asked
     // the runtime for at least 24 queues, GPU_MAX_HW_QUEUES, as bench.py does)
     static const bool many_queues = [] { const char *q = getenv("GPU_MAX_HW_QUEUES"); return q && atoi(q) >= 24; }();
-    const bool split = band && d_order && n_big > 0 && n_big < cnt && !getenv("XPNG_NARROW_WALK") && !getenv("XPNG_NO_SPLIT") &&
+    const bool split = band && d_order && n_big > 0 && n_big < cnt && !probe_env("XPNG_NARROW_WALK") && !getenv("XPNG_NO_SPLIT") &&
                        (many_queues || getenv("XPNG_SPLIT"));
     const uint32_t jb = split ? n_big * B : 0;
-    const uint32_t nostore = getenv("XPNG_DBG_NOSTORE") ? 1u : 0u;
+    const uint32_t nostore = probe_env("XPNG_DBG_NOSTORE") ? 1u : 0u;
     // Occupancy limiter of the band reconstruction: 12 KB of unused LDS per wave keep it at ~10 waves per CU.  Its scattered
     // 16-byte loads and stores (64 rows per instruction) fill the memory pipeline's queues, and the chain kernels of the other
     // pipeline slots, which touch memory once per 8-step block, then wait for their words: decode-only rate at 3 slots
     // 43 -> 51 Gpx/s, combined bench +4 % (XPNG_RECON_LDS_PAD=0 turns it off)
-    const size_t dbg_pad = getenv("XPNG_RECON_LDS_PAD") ? (size_t)atoi(getenv("XPNG_RECON_LDS_PAD")) : 0;
-    const size_t pad_rs = getenv("XPNG_PAD_RS") ? (size_t)atoi(getenv("XPNG_PAD_RS")) : 0;
+    const size_t dbg_pad = probe_pad("XPNG_RECON_LDS_PAD");
+    const size_t pad_rs = probe_pad("XPNG_PAD_RS");
     if (split) {
         if (!ws.side2) {
             if (chain_stream_create(&ws.side2) != hipSuccess ||
@@ -1572,7 +1575,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
-        if (dbg_skip("walk_big")) {} else if (getenv("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
         else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
@@ -1583,7 +1586,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
             k_dec_recon_band<3><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
-    } else if (wide && !getenv("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
+    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4) {

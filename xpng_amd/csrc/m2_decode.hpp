@@ -459,6 +459,10 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const uint32_t cnt = t1 - t0, total = B * cnt;
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, nullptr};
     if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
+    if (!ws.d_off || !ws.d_nlseq || !ws.d_resid || !d_info2 || !d_blk2 || !d_tabs2 || !d_scratch2 || !d_sbase2 || !d_tiles || !d_blob_ptrs || !d_raster_ptrs) {
+        err = "internal error: a mode-2 decode workspace buffer was never allocated";  // (a null pointer in a kernel is a GPU fault = abort())
+        return 1;
+    }
     const uint64_t bpr = W * 3;
     if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }
     k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2, d_status);
@@ -467,11 +471,11 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
     } else if (m2_wide_decode(ws, B, n_tiles, total, d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, s, err)) return 1;
     k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);
-    if ((uint64_t)total * M2_STREAMS > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m2_dec_resid<256><<<total, 256, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
+    if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_dec_resid<256><<<total, 256, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
     else k_m2_dec_resid<1024><<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
-    const bool wide_recon = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * M2_STREAMS > 2048 || getenv("XPNG_WIDE_RANS")) && max_w <= RB_MAXW && !getenv("XPNG_WAVEFRONT_RECON");
+    const bool wide_recon = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * M2_STREAMS > 2048 || getenv("XPNG_WIDE_RANS")) && max_w <= RB_MAXW && !probe_env("XPNG_WAVEFRONT_RECON");
     if (wide_recon) k_m2_dec_recon_band<<<total, 64, RB_LDS_BYTES(max_w), s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr);
     else k_m2_dec_recon<<<total, rthreads, rlds, s>>>(d_info2, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, free_ew);
     if (hipGetLastError() != hipSuccess) { err = "mode-2 decode kernel launch failed"; return 1; }

@@ -1,24 +1,28 @@
 // wrappers.hpp -- the host-buffer entry points of include/xpng_hip.h (included by xpng_hip.hip): what the host C driver
 // calls in place of the reference's two thread fan-outs (libxpng.c:758 + 764-769, 982-983).
 //
+//   * RE-ENTRANT, like the reference (SURVEY 8(b) "Threading": no globals, every call spawns and joins its own workers,
+//     until_fork/4_letters.c:9-17).  A call owns everything it touches: it CHECKS OUT a context (tile table + workspace + stream)
+//     and, for xpng_store, a staged-image object from a pool of idle ones, works on them without any lock, and hands them back.
+//     The pool's mutex is held only while an object is taken out or put back - never across a HIP call - so two host threads
+//     in xpng_store / xpng_load run side by side on two contexts and two streams.
 //   * One process, up to T devices.  The reference's `T` is its worker count (libxpng.c:146-151: T = min(T, N) threads over a
 //     shared tile cursor); here T devices each take one contiguous, pixel-weighted tile range (the same split as
-//     xpng_amd/shard.py), encode / decode it from their own band of the raster, and the blob ranges are gathered on device 0 by
-//     peer copies over xGMI for the one concatenation (libxpng.c:764-769) before the single copy to the host.
-//   * Contexts (tile table + workspace per geometry, device and tile range) are kept in a small LRU, and every staging
-//     buffer lives in its context and only ever grows: repeat calls allocate nothing.
+//     xpng_amd/shard.py), encode / decode it from their own band of the raster, and the blob ranges are gathered on the first
+//     device by peer copies over xGMI for the one concatenation (libxpng.c:764-769) before the single copy to the host.
+//     T == 0 ("auto") means ONE device: the multi-device path has never run on real peers (SCALE skipped in every round so
+//     far), so it is opt-in - T > 1, or XPNG_GPUS=n for T == 0 - until a byte-parity run on hardware exists.
+//   * Idle contexts keep their staging buffers, which only ever grow: repeat calls allocate nothing.
 //   * Everything runs on explicit devices (XPNG_DEVICE = first device, default 0) and the caller's current device is restored.
 #pragma once
-
-static std::mutex g_mu;
 
 static int base_device() {
     static const int d = [] { const char *e = getenv("XPNG_DEVICE"); return e ? atoi(e) : 0; }();
     return d;
 }
-// XPNG_FAKE_DEVICES=n: rehearse the multi-device path on a box with one GPU (n shards, all on the base device)
+// (probe builds) XPNG_FAKE_DEVICES=n: rehearse the multi-device path on a box with one GPU (n shards, all on the base device)
 static int fake_devices() {
-    const char *e = getenv("XPNG_FAKE_DEVICES");
+    const char *e = probe_env("XPNG_FAKE_DEVICES");
     return e ? atoi(e) : 0;
 }
 static int usable_devices() {
@@ -46,41 +50,65 @@ static uint64_t tile_count_for(uint64_t W, uint64_t H) {
     return nx * ny;
 }
 
-// ---- context cache -----------------------------------------------------------------------------------------
-static std::vector<xpnghip_ctx *> g_lru;  // most recently used first
-static uint64_t g_call = 0;               // contexts touched by the call in progress (ctx->call == g_call) are never evicted
-constexpr size_t LRU_MAX = 12;
-constexpr uint64_t LRU_MAX_BYTES = 64ull << 30;
-static void lru_trim(size_t keep, uint64_t keep_bytes) {
+// ---- pool of idle contexts ------------------------------------------------------------------------------------
+// g_pool_mu guards the three idle lists below and nothing else; no HIP call is made while it is held.
+static std::mutex g_pool_mu;
+static std::vector<xpnghip_ctx *> g_idle;  // most recently used first
+constexpr size_t POOL_MAX = 12;
+constexpr uint64_t POOL_MAX_BYTES = 64ull << 30;
+
+// takes every idle context beyond `keep` entries / `keep_bytes` out of the pool; the caller destroys them (outside the lock)
+static std::vector<xpnghip_ctx *> pool_trim_locked(size_t keep, uint64_t keep_bytes) {
+    std::vector<xpnghip_ctx *> kept, victims;
     uint64_t sum = 0;
-    std::vector<xpnghip_ctx *> kept;
-    for (xpnghip_ctx *c : g_lru) {
-        sum += c->ws_bytes;
-        if (c->call == g_call || (kept.size() < keep && sum <= keep_bytes)) kept.push_back(c);
-        else xpnghip_ctx_destroy(c);
+    for (xpnghip_ctx *c : g_idle) {
+        sum += c->ws_bytes + c->cap_raster + c->cap_blobs + c->cap_blob_in;
+        if (kept.size() < keep && sum <= keep_bytes) kept.push_back(c); else victims.push_back(c);
     }
-    g_lru.swap(kept);
+    g_idle.swap(kept);
+    return victims;
 }
-static xpnghip_ctx *cached_ctx(int dev, uint64_t w, uint64_t h, int pxsz, uint64_t r0 = 0, uint64_t r1 = ~0ull) {
-    for (size_t i = 0; i < g_lru.size(); i++) {
-        xpnghip_ctx *c = g_lru[i];
-        if (c->device == dev && c->W == w && c->H == h && c->pxsz == pxsz && c->r0 == r0 && c->r1 == std::min<uint64_t>(r1, c->tiles.size())) {
-            g_lru.erase(g_lru.begin() + (long)i);
-            g_lru.insert(g_lru.begin(), c);
-            c->call = g_call;
-            return c;
+static xpnghip_ctx *ctx_checkout(int dev, uint64_t w, uint64_t h, int pxsz, uint64_t r0 = 0, uint64_t r1 = ~0ull) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_idle.size(); i++) {
+            xpnghip_ctx *c = g_idle[i];
+            if (c->device == dev && c->W == w && c->H == h && c->pxsz == pxsz && c->r0 == r0 && c->r1 == std::min<uint64_t>(r1, c->tiles.size())) {
+                g_idle.erase(g_idle.begin() + (long)i);
+                return c;
+            }
         }
     }
     xpnghip_ctx *c = nullptr;
     if (xpnghip_ctx_create_range(&c, dev, w, h, pxsz, 1, r0, r1)) {
-        lru_trim(0, 0);  // out of memory, perhaps: give the cached workspaces back and try once more
+        // out of memory, perhaps: give the idle workspaces back and try once more
+        std::vector<xpnghip_ctx *> victims;
+        { std::lock_guard<std::mutex> lk(g_pool_mu); victims = pool_trim_locked(0, 0); }
+        for (xpnghip_ctx *v : victims) xpnghip_ctx_destroy(v);
         if (xpnghip_ctx_create_range(&c, dev, w, h, pxsz, 1, r0, r1)) return nullptr;
     }
-    c->call = g_call;
-    g_lru.insert(g_lru.begin(), c);
-    lru_trim(LRU_MAX, LRU_MAX_BYTES);
     return c;
 }
+static void ctx_checkin(xpnghip_ctx *c) {
+    if (!c) return;
+    std::vector<xpnghip_ctx *> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_idle.insert(g_idle.begin(), c);
+        victims = pool_trim_locked(POOL_MAX, POOL_MAX_BYTES);
+    }
+    for (xpnghip_ctx *v : victims) xpnghip_ctx_destroy(v);
+}
+struct CtxLease {  // a context for the duration of one call
+    xpnghip_ctx *c = nullptr;
+    CtxLease() = default;
+    explicit CtxLease(xpnghip_ctx *p) : c(p) {}
+    CtxLease(const CtxLease &) = delete;
+    CtxLease &operator=(const CtxLease &) = delete;
+    CtxLease(CtxLease &&o) noexcept : c(o.c) { o.c = nullptr; }
+    ~CtxLease() { ctx_checkin(c); }
+};
+
 static int ensure_buf(uint8_t *&p, uint64_t &cap, uint64_t need) {
     if (cap >= need && p) return 0;
     if (p) (void)hipFree(p);
@@ -92,40 +120,99 @@ static int ensure_buf(uint8_t *&p, uint64_t &cap, uint64_t need) {
 
 // ---- tile ranges of a multi-device call -----------------------------------------------------------------------
 struct Shard { int dev; uint64_t r0, r1; uint32_t y0, y1; xpnghip_ctx *c; uint64_t len, off; };
-// how many devices a call uses: T >= 1 -> min(T, usable, N); T == 0 -> as many as leave each device at least 256 tiles (a
-// single image is bound by its longest entropy chain, not by tile count: spreading 81 tiles over 8 devices buys nothing)
+// how many devices a call uses: T >= 1 -> min(T, usable, N); T == 0 -> ONE (see the header comment), or XPNG_GPUS
 static int devices_for(uint64_t T, uint64_t N) {
     const int have = usable_devices();
     if (have < 1) return 0;
-    uint64_t d = T ? T : std::max<uint64_t>(1, N / 256);
+    uint64_t d = T ? T : 1;
     if (const char *e = getenv("XPNG_GPUS")) if (!T && atoi(e) > 0) d = (uint64_t)atoi(e);
     d = std::min<uint64_t>(d, (uint64_t)have);
     d = std::min<uint64_t>(d, N);
     return (int)std::max<uint64_t>(d, 1);
 }
-// contiguous ranges balanced by pixel count (xpng_amd/shard.py weighted_tile_ranges; the reference's cursor hands out tiles
-// one by one, libxpng.c:150-151 - any partition gives the same bytes)
-static std::vector<Shard> make_shards(const std::vector<TileDesc> &tiles, int D) {
-    std::vector<Shard> out;
+// Contiguous ranges balanced by pixel count: range k ends at the first tile where the running pixel count reaches k/D of the
+// total, and every range keeps at least one tile (xpng_amd/shard.py weighted_tile_ranges is the same rule; the reference's
+// cursor hands out tiles one by one, libxpng.c:150-151 - any partition gives the same bytes).
+static void shard_ranges(const std::vector<TileDesc> &tiles, int D, std::vector<std::pair<uint64_t, uint64_t>> &out) {
+    out.clear();
+    const uint64_t N = tiles.size();
+    if (D < 1) D = 1;
+    if ((uint64_t)D > N) D = (int)N;
     uint64_t total = 0, acc = 0, start = 0;
     for (const TileDesc &t : tiles) total += t.n;
     int k = 1;
-    for (uint64_t i = 0; i < tiles.size(); i++) {
+    for (uint64_t i = 0; i < N && k < D; i++) {
         acc += tiles[i].n;
-        while (k < D && acc * (uint64_t)D >= total * (uint64_t)k && i + 1 <= tiles.size() - (uint64_t)(D - k)) {
-            out.push_back(Shard{0, start, i + 1, 0, 0, nullptr, 0, 0});
+        const uint64_t left = N - (i + 1);  // tiles behind this one: each of the D - k later ranges needs one
+        if (acc * (uint64_t)D >= total * (uint64_t)k || left == (uint64_t)(D - k)) {
+            out.emplace_back(start, i + 1);
             start = i + 1; k++;
         }
     }
-    out.push_back(Shard{0, start, tiles.size(), 0, 0, nullptr, 0, 0});
-    for (size_t s = 0; s < out.size(); s++) {
-        Shard &sh = out[s];
-        sh.dev = shard_device((int)s);
+    out.emplace_back(start, N);
+}
+static std::vector<Shard> make_shards(const std::vector<TileDesc> &tiles, int D) {
+    std::vector<std::pair<uint64_t, uint64_t>> rr;
+    shard_ranges(tiles, D, rr);
+    std::vector<Shard> out;
+    for (size_t s = 0; s < rr.size(); s++) {
+        Shard sh{shard_device((int)s), rr[s].first, rr[s].second, 0, 0, nullptr, 0, 0};
         uint32_t y0 = ~0u, y1 = 0;
         for (uint64_t i = sh.r0; i < sh.r1; i++) { y0 = std::min(y0, tiles[i].y); y1 = std::max(y1, tiles[i].y + tiles[i].h); }
         sh.y0 = y0; sh.y1 = y1;
+        out.push_back(sh);
     }
     return out;
+}
+// host-only (no device needed): the tile ranges a call on D devices would use, for the CPU tests that cross-check this
+// split against xpng_amd/shard.py; ranges[2k], ranges[2k+1] = [r0, r1) of device k.  Returns the number of ranges.
+extern "C" int xpnghip_shard_ranges(uint64_t w, uint64_t h, int D, uint64_t *ranges, int cap) {
+    try {
+        if (!w || !h || w > (1u << 24) || h > (1u << 24) || D < 1 || !ranges) return -1;
+        std::vector<TileDesc> tiles;
+        build_tiles(w, h, tiles);
+        std::vector<std::pair<uint64_t, uint64_t>> rr;
+        shard_ranges(tiles, D, rr);
+        if ((int)rr.size() > cap) return -1;
+        for (size_t k = 0; k < rr.size(); k++) { ranges[2 * k] = rr[k].first; ranges[2 * k + 1] = rr[k].second; }
+        return (int)rr.size();
+    } catch (...) { return -1; }
+}
+
+// Peer access between the gather device and a shard's device: asked once per ordered pair.  hipMemcpyPeerAsync works either
+// way; without peer access the runtime stages the copy through host memory, which the caller should know about: the note is
+// left in xpnghip_last_error() although the call succeeds.
+static bool peer_ready(int a, int b) {
+    if (a == b) return true;
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, int>, bool>> known;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : known) if (e.first.first == a && e.first.second == b) return e.second;
+    }
+    int can = 0;
+    bool ok = hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can;
+    if (ok) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        ok = hipSetDevice(a) == hipSuccess;
+        if (ok) {
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            (void)hipGetLastError();
+        }
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    known.push_back({{a, b}, ok});
+    return ok;
+}
+static void note_peers(const std::vector<Shard> &sh) {
+    std::string note;
+    for (size_t k = 1; k < sh.size(); k++)
+        if (!(peer_ready(sh[0].dev, sh[k].dev) && peer_ready(sh[k].dev, sh[0].dev)))
+            note += (note.empty() ? "note: no peer access between devices " : ", ") + std::to_string(sh[0].dev) + "<->" + std::to_string(sh[k].dev);
+    if (!note.empty()) g_err = note + ": those copies were staged through host memory";
 }
 
 static int check_geometry(uint64_t w, uint64_t h, int pxsz) {
@@ -134,20 +221,25 @@ static int check_geometry(uint64_t w, uint64_t h, int pxsz) {
     return 0;
 }
 
-// Encode on D devices.  The raster is either in host memory (h_src) or already staged on the base device (d_src).
+// Encode on D devices.  The raster is either in host memory (h_src) or already staged on the base device (d_src; the caller
+// has synchronised the stream that produced it).
 static int encode_multi(int D, int mode, const uint8_t *h_src, const uint8_t *d_src, uint64_t w, uint64_t h, int pxsz, uint8_t **blobs, uint64_t *blobs_len) {
     const uint64_t bpr = w * (uint64_t)pxsz;
     std::vector<TileDesc> tiles;
     build_tiles(w, h, tiles);
     std::vector<Shard> sh = make_shards(tiles, D);
+    std::vector<CtxLease> leases;
+    leases.reserve(sh.size());
     const int dev0 = sh[0].dev;
+    note_peers(sh);
     // shard 0 encodes straight into the gather buffer (sized for the whole image), the others into their own
     uint64_t whole_bound = 16;
     for (const TileDesc &t : tiles) whole_bound += (uint64_t)t.n * pxsz + 4;
     for (size_t k = 0; k < sh.size(); k++) {
         Shard &s = sh[k];
         HIPCHK(hipSetDevice(s.dev));
-        if (!(s.c = cached_ctx(s.dev, w, h, pxsz, s.r0, s.r1))) return 1;
+        if (!(s.c = ctx_checkout(s.dev, w, h, pxsz, s.r0, s.r1))) return 1;
+        leases.emplace_back(s.c);
         xpnghip_ctx *c = s.c;
         const uint64_t band = (uint64_t)(s.y1 - s.y0) * bpr;
         if (ensure_buf(c->d_raster, c->cap_raster, band + 16)) return 1;
@@ -185,14 +277,13 @@ static int encode_multi(int D, int mode, const uint8_t *h_src, const uint8_t *d_
 static int encode_tiles_impl(uint64_t T, int mode, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz, uint8_t **blobs, uint64_t *blobs_len) {
     if (!raster || !blobs || !blobs_len) return fail("null argument");
     if (check_geometry(w, h, pxsz)) return 1;
-    std::lock_guard<std::mutex> lk(g_mu);
     DevGuard guard;
-    g_call++;
     const uint64_t N = tile_count_for(w, h);
     const int D = devices_for(T, N);
     if (D > 1) return encode_multi(D, mode, raster, nullptr, w, h, pxsz, blobs, blobs_len);
     HIPCHK(hipSetDevice(base_device()));
-    xpnghip_ctx *c = cached_ctx(base_device(), w, h, pxsz);
+    CtxLease lease(ctx_checkout(base_device(), w, h, pxsz));
+    xpnghip_ctx *c = lease.c;
     if (!c) return 1;
     const uint64_t s = w * h * (uint64_t)pxsz;
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blobs, c->cap_blobs, xpnghip_ctx_blob_bound(c, 0, N))) return 1;
@@ -201,7 +292,7 @@ static int encode_tiles_impl(uint64_t T, int mode, const uint8_t *raster, uint64
     if (xpnghip_encode_device(c, mode, c->d_raster, 0, N, c->d_blobs, &len, nullptr)) return 1;
     uint8_t *out = (uint8_t *)malloc(len ? len : 1);
     if (!out) return fail("malloc failed");
-    if (hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost) != hipSuccess) { free(out); return fail("blob download failed"); }
+    if (hipMemcpyAsync(out, c->d_blobs, len, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { free(out); return fail("blob download failed"); }
     *blobs = out; *blobs_len = len;
     return 0;
 }
@@ -213,10 +304,13 @@ static int decode_multi(int D, int mode, const uint8_t *blobs, const std::vector
     std::vector<TileDesc> tiles;
     build_tiles(w, h, tiles);
     std::vector<Shard> sh = make_shards(tiles, D);
+    std::vector<CtxLease> leases;
+    leases.reserve(sh.size());
     std::vector<uint64_t> rel;
     for (Shard &s : sh) {
         HIPCHK(hipSetDevice(s.dev));
-        if (!(s.c = cached_ctx(s.dev, w, h, pxsz, s.r0, s.r1))) return 1;
+        if (!(s.c = ctx_checkout(s.dev, w, h, pxsz, s.r0, s.r1))) return 1;
+        leases.emplace_back(s.c);
         xpnghip_ctx *c = s.c;
         s.off = off[s.r0]; s.len = off[s.r1] - off[s.r0];
         const uint64_t band = (uint64_t)(s.y1 - s.y0) * bpr;
@@ -247,6 +341,27 @@ static int decode_multi(int D, int mode, const uint8_t *blobs, const std::vector
     return rc;
 }
 
+// Touches the caller's (typically freshly malloc()ed) raster, one write per page, on a few helper threads while the kernels
+// run: its first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.  The
+// raster is the call's output buffer - its contents are undefined until the call returns 0 - so writing zeros early is
+// harmless; if a helper thread cannot be created the pages simply fault during the copy.
+struct Prefault {
+    static constexpr int NT = 4;
+    std::thread th[NT];
+    int started = 0;
+    void start(uint8_t *raster, uint64_t s) {
+        const uint64_t part = ((s / NT) + 4095) & ~4095ull;
+        for (int t = 0; t < NT; t++) {
+            const uint64_t a = std::min<uint64_t>(s, t * part), b = std::min<uint64_t>(s, (t + 1) * part);
+            try { th[t] = std::thread([=] { for (uint64_t o = a; o < b; o += 4096) raster[o] = 0; }); }
+            catch (...) { return; }  // (std::system_error: no more threads - the ones already started are joined below)
+            started = t + 1;
+        }
+    }
+    void join() { for (int t = 0; t < started; t++) if (th[t].joinable()) th[t].join(); started = 0; }
+    ~Prefault() { join(); }  // (a joinable std::thread must never be destroyed: that is std::terminate, past every catch)
+};
+
 static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h, int pxsz, uint8_t *raster) {
     if (!raster || !blobs) return fail("null argument");
     if (check_geometry(w, h, pxsz)) return 1;
@@ -262,35 +377,26 @@ static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_
     }
     if (o > blobs_len) return fail("truncated file: last tile runs past the end");
     off[N] = o;
-    std::lock_guard<std::mutex> lk(g_mu);
     DevGuard guard;
-    g_call++;
     const int D = devices_for(T, N);
     if (D > 1) return decode_multi(D, mode, blobs, off, w, h, pxsz, raster);
     HIPCHK(hipSetDevice(base_device()));
-    xpnghip_ctx *c = cached_ctx(base_device(), w, h, pxsz);
+    CtxLease lease(ctx_checkout(base_device(), w, h, pxsz));
+    xpnghip_ctx *c = lease.c;
     if (!c) return 1;
     const uint64_t s = w * h * (uint64_t)pxsz;
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blob_in, c->cap_blob_in, blobs_len)) return 1;
     HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream));
     if (xpnghip_decode_device(c, mode, c->d_blob_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr)) return 1;
-    // While the kernels run: touch the caller's (typically freshly malloc()ed) raster, one write per page, on a few threads.  Its
-    // first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.
-    if (s >= (32u << 20) && !getenv("XPNG_NO_PREFAULT")) {
-        constexpr int NT = 4;
-        std::thread th[NT];
-        const uint64_t part = ((s / NT) + 4095) & ~4095ull;
-        for (int t = 0; t < NT; t++) {
-            const uint64_t a = std::min<uint64_t>(s, t * part), b = std::min<uint64_t>(s, (t + 1) * part);
-            th[t] = std::thread([=] { for (uint64_t o = a; o < b; o += 4096) raster[o] = 0; });
-        }
-        for (int t = 0; t < NT; t++) th[t].join();
-    }
+    Prefault pf;
+    if (s >= (32u << 20) && !probe_env("XPNG_NO_PREFAULT")) pf.start(raster, s);
     const int st = xpnghip_ctx_decode_status(c, nullptr);
+    pf.join();
     if (st == 1) return fail("corrupt file: a tile header is inconsistent with the tile table");
     if (st != 0) return fail("decode failed");
     // (a pinned staging buffer with chunked copies and host copy threads measured no better than this plain copy: 21.8 against 21.5 ms)
-    HIPCHK(hipMemcpy(raster, c->d_raster, s, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(raster, c->d_raster, s, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -313,8 +419,26 @@ extern "C" int xpnghip_decode_tiles(int mode, const uint8_t *blobs, uint64_t blo
     XPNG_GUARDED(decode_tiles_impl(1, mode, blobs, blobs_len, w, h, pxsz, raster))
 }
 
-// ---- staged image (normalize_RGBA and the single-colour test on the device) ---------------------------
-static uint32_t *g_flags = nullptr;  // 4 device words for the OR-reductions (base device)
+// ---- normalize_RGBA and the single-colour test on the device ---------------------------------------------------
+// 16-byte flag blocks for the OR-reductions, per device: checked out for a call and put back, never freed per call (hipFree
+// synchronises the whole device: a pipelined caller of xpnghip_normalize_device would stall all its streams on every call).
+static std::vector<std::pair<int, uint32_t *>> g_idle_flags;  // (device, block); guarded by g_pool_mu
+static uint32_t *flags_checkout(int dev) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_idle_flags.size(); i++)
+            if (g_idle_flags[i].first == dev) { uint32_t *p = g_idle_flags[i].second; g_idle_flags.erase(g_idle_flags.begin() + (long)i); return p; }
+    }
+    uint32_t *p = nullptr;
+    if (hipMalloc((void **)&p, 16) != hipSuccess) return nullptr;
+    return p;
+}
+static void flags_checkin(int dev, uint32_t *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_idle_flags.push_back({dev, p});
+}
+
 static int norm_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, hipStream_t s, uint32_t *flags) {
     HIPCHK(hipMemsetAsync(flags, 0, 16, s));
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((npx / 4 + 255) / 256 + 1, 256 * 16);
@@ -328,107 +452,170 @@ static int norm_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_
     HIPCHK(hipGetLastError());
     return 0;
 }
-extern "C" int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream) {
+static int normalize_device_impl(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream) {
     if (!d_rgba || !d_out || !pxsz_out || !rewritten || !npx) return fail("null argument");
     if (((uintptr_t)d_rgba & 15) || ((uintptr_t)d_out & 3)) return fail("device buffers must be 16-byte aligned");
-    // (the caller's raster lives on the caller's current device: the flag words are allocated there, per call)
-    uint32_t *flags = nullptr;
-    HIPCHK(hipMalloc((void **)&flags, 16));
+    int dev = 0;  // (the caller's raster lives on the caller's current device: so does the flag block)
+    HIPCHK(hipGetDevice(&dev));
+    uint32_t *flags = flags_checkout(dev);
+    if (!flags) return fail("hipMalloc failed (flag block)");
+    // (norm_device has read the flags back - a stream synchronisation - before it returns: the block is idle again)
     const int rc = norm_device(d_rgba, npx, d_out, pxsz_out, rewritten, (hipStream_t)stream, flags);
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(flags);
+    flags_checkin(dev, flags);
     return rc;
 }
+extern "C" int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *d_out, int *pxsz_out, int *rewritten, void *stream) {
+    XPNG_GUARDED(normalize_device_impl(d_rgba, npx, d_out, pxsz_out, rewritten, stream))
+}
 
-static struct Staged {
-    bool open = false;
-    int prev_dev = -1;
+// ---- staged image ------------------------------------------------------------------------------------------------
+// One object per xpng_store call in flight (include/xpng_hip.h): upload buffer, rewrite buffer, flag block and a stream of its
+// own.  Idle objects are pooled with their buffers.
+struct xpnghip_image {
+    int dev = 0;
     uint64_t w = 0, h = 0, cap_in = 0, cap_norm = 0;
     int pxsz = 0;
     uint8_t *d_in = nullptr, *d_norm = nullptr;  // uploaded raster; rewritten raster (when normalisation changed it)
     const uint8_t *cur = nullptr;                // the staged (normalised) raster
-} g_img;
-
-static int image_begin_impl(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
-    // (g_mu is held; on failure the caller releases it)
-    if (hipGetDevice(&g_img.prev_dev) != hipSuccess) g_img.prev_dev = -1;
-    HIPCHK(hipSetDevice(base_device()));
-    const uint64_t s = w * h * (uint64_t)pxsz_in;
-    if (ensure_buf(g_img.d_in, g_img.cap_in, s)) return 1;
-    HIPCHK(hipMemcpy(g_img.d_in, raster, s, hipMemcpyHostToDevice));
-    g_img.w = w; g_img.h = h; g_img.pxsz = pxsz_in; g_img.cur = g_img.d_in;
-    if (pxsz_in == 4) {
-        if (ensure_buf(g_img.d_norm, g_img.cap_norm, s)) return 1;
-        if (!g_flags) HIPCHK(hipMalloc((void **)&g_flags, 16));
-        int rewritten = 0;
-        if (norm_device(g_img.d_in, w * h, g_img.d_norm, &g_img.pxsz, &rewritten, nullptr, g_flags)) return 1;
-        if (rewritten) g_img.cur = g_img.d_norm;
+    uint32_t *flags = nullptr;
+    hipStream_t stream = nullptr;
+};
+static std::vector<xpnghip_image *> g_idle_images;  // guarded by g_pool_mu
+constexpr size_t IMAGE_POOL_MAX = 4;
+static void image_destroy(xpnghip_image *im) {
+    if (!im) return;
+    (void)hipSetDevice(im->dev);
+    if (im->stream) { (void)hipStreamSynchronize(im->stream); (void)hipStreamDestroy(im->stream); }
+    if (im->d_in) (void)hipFree(im->d_in);
+    if (im->d_norm) (void)hipFree(im->d_norm);
+    if (im->flags) (void)hipFree(im->flags);
+    delete im;
+}
+static xpnghip_image *image_checkout(int dev) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_idle_images.size(); i++)
+            if (g_idle_images[i]->dev == dev) { xpnghip_image *im = g_idle_images[i]; g_idle_images.erase(g_idle_images.begin() + (long)i); return im; }
     }
-    *pxsz_out = g_img.pxsz;
+    xpnghip_image *im = new xpnghip_image();
+    im->dev = dev;
+    if (hipStreamCreateWithFlags(&im->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&im->flags, 16) != hipSuccess) { image_destroy(im); return nullptr; }
+    return im;
+}
+static void image_checkin(xpnghip_image *im) {
+    xpnghip_image *victim = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_idle_images.insert(g_idle_images.begin(), im);
+        if (g_idle_images.size() > IMAGE_POOL_MAX) { victim = g_idle_images.back(); g_idle_images.pop_back(); }
+    }
+    image_destroy(victim);
+}
+
+static int image_begin_impl(xpnghip_image **out, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
+    if (!out || !raster || !pxsz_out) return fail("bad argument");
+    *out = nullptr;
+    if (check_geometry(w, h, pxsz_in)) return 1;
+    DevGuard guard;
+    HIPCHK(hipSetDevice(base_device()));
+    xpnghip_image *im = image_checkout(base_device());
+    if (!im) return fail("staging object allocation failed");
+    auto body = [&]() -> int {
+        const uint64_t s = w * h * (uint64_t)pxsz_in;
+        if (ensure_buf(im->d_in, im->cap_in, s)) return 1;
+        HIPCHK(hipMemcpyAsync(im->d_in, raster, s, hipMemcpyHostToDevice, im->stream));
+        im->w = w; im->h = h; im->pxsz = pxsz_in; im->cur = im->d_in;
+        if (pxsz_in == 4) {
+            if (ensure_buf(im->d_norm, im->cap_norm, s)) return 1;
+            int rewritten = 0;
+            if (norm_device(im->d_in, w * h, im->d_norm, &im->pxsz, &rewritten, im->stream, im->flags)) return 1;
+            if (rewritten) im->cur = im->d_norm;
+        }
+        return 0;
+    };
+    if (body()) { (void)hipStreamSynchronize(im->stream); image_checkin(im); return 1; }
+    *pxsz_out = im->pxsz;
+    *out = im;
     return 0;
 }
-extern "C" int xpnghip_image_begin(const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
-    if (!raster || !pxsz_out) return fail("bad argument");
-    if (check_geometry(w, h, pxsz_in)) return 1;
-    g_mu.lock();
-    const int rc = image_begin_impl(raster, w, h, pxsz_in, pxsz_out);
-    if (rc) {
-        if (g_img.prev_dev >= 0) (void)hipSetDevice(g_img.prev_dev);
-        g_mu.unlock();
-        return rc;
-    }
-    g_img.open = true;
-    return 0;  // (the lock stays held until xpnghip_image_end)
+extern "C" int xpnghip_image_begin(xpnghip_image **img, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
+    XPNG_GUARDED(image_begin_impl(img, raster, w, h, pxsz_in, pxsz_out))
 }
-extern "C" void xpnghip_image_end(void) {
-    if (!g_img.open) return;
-    g_img.open = false;
-    if (g_img.prev_dev >= 0) (void)hipSetDevice(g_img.prev_dev);
-    g_mu.unlock();
+extern "C" void xpnghip_image_end(xpnghip_image *im) {
+    if (!im) return;
+    try {
+        DevGuard guard;
+        (void)hipSetDevice(im->dev);
+        (void)hipStreamSynchronize(im->stream);
+        image_checkin(im);
+    } catch (...) {}
 }
-extern "C" int xpnghip_image_single_colour(int *single) {
-    if (!g_img.open || !single) return fail("no staged image");
-    HIPCHK(hipSetDevice(base_device()));
-    const uint64_t n = g_img.w * g_img.h;
+static int image_single_colour_impl(xpnghip_image *im, int *single) {
+    if (!im || !single) return fail("no staged image");
+    DevGuard guard;
+    HIPCHK(hipSetDevice(im->dev));
+    const uint64_t n = im->w * im->h;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-    if (!g_flags) HIPCHK(hipMalloc((void **)&g_flags, 16));
-    HIPCHK(hipMemsetAsync(g_flags + 2, 0, 4, nullptr));
-    if (g_img.pxsz == 4) k_any_differs<4><<<blocks, 256>>>(g_img.cur, n, g_flags + 2);
-    else k_any_differs<3><<<blocks, 256>>>(g_img.cur, n, g_flags + 2);
+    HIPCHK(hipMemsetAsync(im->flags + 2, 0, 4, im->stream));
+    if (im->pxsz == 4) k_any_differs<4><<<blocks, 256, 0, im->stream>>>(im->cur, n, im->flags + 2);
+    else k_any_differs<3><<<blocks, 256, 0, im->stream>>>(im->cur, n, im->flags + 2);
     uint32_t f = 0;
-    HIPCHK(hipMemcpy(&f, g_flags + 2, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&f, im->flags + 2, 4, hipMemcpyDeviceToHost, im->stream));
+    HIPCHK(hipStreamSynchronize(im->stream));
     *single = f ? 0 : 1;
     return 0;
 }
-extern "C" int xpnghip_image_fetch(uint8_t *dst) {
-    if (!g_img.open || !dst) return fail("no staged image");
-    HIPCHK(hipSetDevice(base_device()));
-    HIPCHK(hipMemcpy(dst, g_img.cur, g_img.w * g_img.h * (uint64_t)g_img.pxsz, hipMemcpyDeviceToHost));
+extern "C" int xpnghip_image_single_colour(xpnghip_image *im, int *single) { XPNG_GUARDED(image_single_colour_impl(im, single)) }
+static int image_fetch_impl(xpnghip_image *im, uint8_t *dst) {
+    if (!im || !dst) return fail("no staged image");
+    DevGuard guard;
+    HIPCHK(hipSetDevice(im->dev));
+    HIPCHK(hipMemcpyAsync(dst, im->cur, im->w * im->h * (uint64_t)im->pxsz, hipMemcpyDeviceToHost, im->stream));
+    HIPCHK(hipStreamSynchronize(im->stream));
     return 0;
 }
-static int image_encode_impl(uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len) {
-    if (!g_img.open || !blobs || !blobs_len) return fail("no staged image");
-    HIPCHK(hipSetDevice(base_device()));
-    HIPCHK(hipDeviceSynchronize());  // (staging ran on the null stream)
-    g_call++;
-    const uint64_t N = tile_count_for(g_img.w, g_img.h);
+extern "C" int xpnghip_image_fetch(xpnghip_image *im, uint8_t *dst) { XPNG_GUARDED(image_fetch_impl(im, dst)) }
+static int image_encode_impl(xpnghip_image *im, uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len) {
+    if (!im || !blobs || !blobs_len) return fail("no staged image");
+    DevGuard guard;
+    HIPCHK(hipSetDevice(im->dev));
+    const uint64_t N = tile_count_for(im->w, im->h);
     const int D = devices_for(T, N);
-    if (D > 1) return encode_multi(D, mode, nullptr, g_img.cur, g_img.w, g_img.h, g_img.pxsz, blobs, blobs_len);
-    xpnghip_ctx *c = cached_ctx(base_device(), g_img.w, g_img.h, g_img.pxsz);
+    if (D > 1) {
+        HIPCHK(hipStreamSynchronize(im->stream));  // (the shards' streams read the staged raster)
+        return encode_multi(D, mode, nullptr, im->cur, im->w, im->h, im->pxsz, blobs, blobs_len);
+    }
+    CtxLease lease(ctx_checkout(im->dev, im->w, im->h, im->pxsz));
+    xpnghip_ctx *c = lease.c;
     if (!c) return 1;
     if (ensure_buf(c->d_blobs, c->cap_blobs, xpnghip_ctx_blob_bound(c, 0, N))) return 1;
     uint64_t len = 0;
-    if (xpnghip_encode_device(c, mode, g_img.cur, 0, N, c->d_blobs, &len, nullptr)) return 1;
+    // on the image's stream: ordered behind the upload and the normalisation without a device-wide synchronisation
+    if (xpnghip_encode_device(c, mode, im->cur, 0, N, c->d_blobs, &len, im->stream)) return 1;
     uint8_t *out = (uint8_t *)malloc(len ? len : 1);
     if (!out) return fail("malloc failed");
-    if (hipMemcpy(out, c->d_blobs, len, hipMemcpyDeviceToHost) != hipSuccess) { free(out); return fail("blob download failed"); }
+    if (hipMemcpyAsync(out, c->d_blobs, len, hipMemcpyDeviceToHost, im->stream) != hipSuccess || hipStreamSynchronize(im->stream) != hipSuccess) { free(out); return fail("blob download failed"); }
     *blobs = out; *blobs_len = len;
     return 0;
 }
-extern "C" int xpnghip_image_encode_T(uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len) { XPNG_GUARDED(image_encode_impl(T, mode, blobs, blobs_len)) }
-extern "C" int xpnghip_image_encode(int mode, uint8_t **blobs, uint64_t *blobs_len) { XPNG_GUARDED(image_encode_impl(1, mode, blobs, blobs_len)) }
+extern "C" int xpnghip_image_encode_T(xpnghip_image *im, uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len) { XPNG_GUARDED(image_encode_impl(im, T, mode, blobs, blobs_len)) }
+extern "C" int xpnghip_image_encode(xpnghip_image *im, int mode, uint8_t **blobs, uint64_t *blobs_len) { XPNG_GUARDED(image_encode_impl(im, 1, mode, blobs, blobs_len)) }
 // devices a call with worker count T would use on an image of this geometry (what xpng_store_T prints in its MPx/s line)
 extern "C" int xpnghip_devices_for(uint64_t T, uint64_t w, uint64_t h) {
     if (!w || !h || w > (1u << 24) || h > (1u << 24)) return 0;
     return devices_for(T, tile_count_for(w, h));
+}
+// Gives every pooled object (idle contexts with their workspaces, staging objects, flag blocks) back to the runtime.  Optional:
+// a process may simply exit.  Must not run concurrently with other calls into this library.
+extern "C" void xpnghip_shutdown(void) {
+    try {
+        DevGuard guard;
+        std::vector<xpnghip_ctx *> cs;
+        std::vector<xpnghip_image *> ims;
+        std::vector<std::pair<int, uint32_t *>> fl;
+        { std::lock_guard<std::mutex> lk(g_pool_mu); cs.swap(g_idle); ims.swap(g_idle_images); fl.swap(g_idle_flags); }
+        for (xpnghip_ctx *c : cs) xpnghip_ctx_destroy(c);
+        for (xpnghip_image *im : ims) image_destroy(im);
+        for (auto &f : fl) { (void)hipSetDevice(f.first); (void)hipFree(f.second); }
+    } catch (...) {}
 }

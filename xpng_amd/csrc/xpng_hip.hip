@@ -36,6 +36,25 @@ static int fail(const std::string &m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// A kernel that dereferences a device pointer nobody allocated does not fail - it FAULTS: the ROCm runtime's fault handler prints
+// "Memory access fault by GPU node ..." and calls abort(), past every catch of the extern "C" entry points (that is what took
+// the test process down in gpurun_out/r2_t14.log: a working tree in which the five symbol planes had just become lazily
+// allocated and launch_transform, reached through the mode-2 encode, did not yet call ensure_planes).  So every launch
+// sequence names the workspace buffers it is about to hand to kernels and refuses to launch when one of them is null.
+#define XPNG_REQUIRE(...)                                                                                                    \
+    do {                                                                                                                     \
+        const void *rq_[] = {__VA_ARGS__};                                                                                   \
+        for (const void *q_ : rq_)                                                                                           \
+            if (!q_) return fail("internal error: a workspace buffer of this launch sequence was never allocated (one of: " #__VA_ARGS__ ")"); \
+    } while (0)
+
+// A batched decode forks three streams per context and a pipelined caller keeps several contexts in flight: with the runtime's
+// default of 4 hardware queues those streams share queues and serialise (measured: 31 -> 21 Gpx/s).  The runtime reads
+// GPU_MAX_HW_QUEUES when it initialises - the first HIP call of the process - so the library asks for 32 when it is LOADED,
+// unless the caller has chosen a value.  A process that has already initialised HIP before loading this library keeps what it
+// had (export the variable yourself in that case: INTEGRATION.md).
+__attribute__((constructor)) static void xpnghip_on_load(void) { (void)setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+
 extern "C" int xpnghip_abi_version(void) { return XPNGHIP_ABI_VERSION; }
 extern "C" const char *xpnghip_last_error(void) { return g_err.c_str(); }
 extern "C" int xpnghip_device_count(void) {
@@ -201,7 +220,9 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
     ALLOC(c->d_tile_hdr, VN * 4);
     ALLOC(c->d_off, (VN + batch) * 8);
     ALLOC(c->d_totals, (uint64_t)batch * 8);
-    ALLOC(c->d_dbg, VN * 10 * 8 * 8 * 2);
+#ifdef XPNG_PROBES
+    ALLOC(c->d_dbg, VN * 10 * 8 * 8 * 2);  // phase stamps of the chain kernels (XPNG_STAMPS)
+#endif
     ALLOC(c->d_wprep, VN * 10 * sizeof(WPrep));
     ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096);
     ALLOC(c->d_wtabc, VN * WTC_BYTES + 4096);
@@ -223,7 +244,7 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         c->n_big = 0;
         for (uint32_t i : ord) if ((uint64_t)c->tiles[i].n * 4 >= (uint64_t)c->tiles[ord[0]].n * 3) c->n_big++;
     }
-    c->stamps = getenv("XPNG_STAMPS") != nullptr;
+    c->stamps = c->d_dbg && probe_env("XPNG_STAMPS") != nullptr;  // (probe builds only)
     if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipMemcpy(c->d_tiles, all.data(), VN * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess) {
         xpnghip_ctx_destroy(c);
@@ -280,7 +301,7 @@ static int set_ptrs(xpnghip_ctx *c, const void *const *in, void *const *outp, ui
 
 // the tile-major, size-sorted enumeration applies to launches over the context's whole tile range (XPNG_IMAGE_MAJOR=1: off)
 static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1) {
-    return (t0 == c->r0 && t1 == c->r1 && !getenv("XPNG_IMAGE_MAJOR")) ? c->d_order : nullptr;
+    return (t0 == c->r0 && t1 == c->r1 && !probe_env("XPNG_IMAGE_MAJOR")) ? c->d_order : nullptr;
 }
 
 // the five symbol planes of the unfused form (BASELINE config-2 entry, mode 2, XPNG_UNFUSED): 5 B/px, allocated on first use
@@ -292,13 +313,13 @@ static int ensure_planes(xpnghip_ctx *c) {
 }
 
 // predictor chooser (pp_rgbx).  Launch only.
-// Occupancy throttles of the bandwidth kernels in the pipelined paths (bytes of unused dynamic LDS per workgroup)
-static size_t env_pad(const char *name) { const char *v = getenv(name); return v ? (size_t)atoi(v) : 0; }
+// (probe builds: occupancy throttles of the bandwidth kernels in the pipelined paths, bytes of unused dynamic LDS per workgroup)
 template <int PXSZ>
 static int launch_chooser(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s, size_t pad = 0) {
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};
     const uint64_t bpr = c->W * PXSZ;
+    XPNG_REQUIRE(c->d_in_ptrs, c->d_tiles, c->d_sums);
     if (dbg_skip("chooser")) return 0;
     if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_sums, 0, (uint64_t)nimg * sel.N * 16, s));
     else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_sums + ((uint64_t)b * sel.N + t0) * 4, 0, (uint64_t)cnt * 16, s));
@@ -319,12 +340,13 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
     if (launch_chooser<PXSZ>(c, nimg, t0, t1, s, pad)) return 1;
+    XPNG_REQUIRE(c->d_planes);
     uint32_t max_w = 0, max_h = 0;
     for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
-    if (PXSZ == 4 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
+    if (PXSZ == 4 && max_w <= TR_MAXW && !probe_env("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
         if (!dbg_skip("transform")) k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
-    } else if (PXSZ == 3 && max_w <= TR_MAXW && !getenv("XPNG_GENERIC_TRANSFORM")) {
+    } else if (PXSZ == 3 && max_w <= TR_MAXW && !probe_env("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
         k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
     } else {
@@ -355,7 +377,7 @@ extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *con
 
 template <int PXSZ>
 static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s) {
-    dbg_sequences().fetch_add(1, std::memory_order_relaxed);
+    dbg_count_sequence();
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     const TileSel sel{t0, cnt, (uint32_t)c->tiles.size(), nimg, order_for(c, t0, t1)};
     const uint64_t bpr = c->W * PXSZ;
@@ -368,13 +390,15 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     // the short transform kernel plus a lighter routing kernel do - so the faster form is the default and the leaner one a switch.
     const bool fused = max_w <= TR_MAXW && getenv("XPNG_FUSED") && !getenv("XPNG_UNFUSED");
     const bool narrow = getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"));
-    const bool small_wg = (uint64_t)total * c->spt > 2048 && !getenv("XPNG_BIG_BLOCKS");
+    const bool small_wg = (uint64_t)total * c->spt > 2048 && !probe_env("XPNG_BIG_BLOCKS");
     // RGBA, fused: the alpha symbols come from a small pass of their own (they do not depend on the predictor choice), so the
     // alpha chains start before the chooser has even run; XPNG_ALPHA_IN_FUSED=1: k_m1_fused writes them (one raster read less,
     // the alpha chains start ~5 ms later: measured 16.0 against 13.7 ms per 64 images at 3 slots)
-    const bool alpha_pass = fused && PXSZ == 4 && !getenv("XPNG_ALPHA_IN_FUSED");
-    static const size_t pad_tr = env_pad("XPNG_PAD_TR"), pad_st = env_pad("XPNG_PAD_ST"), pad_ga = env_pad("XPNG_PAD_GA");
+    const bool alpha_pass = fused && PXSZ == 4 && !probe_env("XPNG_ALPHA_IN_FUSED");
+    static const size_t pad_tr = probe_pad("XPNG_PAD_TR"), pad_st = probe_pad("XPNG_PAD_ST"), pad_ga = probe_pad("XPNG_PAD_GA");
     if (!fused && ensure_planes(c)) return 1;  // (before their address is taken below)
+    XPNG_REQUIRE(c->d_aplane, fused ? (const void *)c->d_aplane : (const void *)c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
+                 c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->h_total);
     const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
     const bool alpha_side = !narrow && PXSZ == 4;
     if (alpha_side && !c->enc_side) {
@@ -384,7 +408,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     }
     auto alpha_branch = [&](hipStream_t as) -> int {  // alpha plane -> tables -> chains, on the side stream
         if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, env_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
         return 0;
     };
@@ -421,7 +445,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
         if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, env_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
         if (!dbg_skip("finish")) k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
@@ -457,12 +481,15 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * 3, VN = (uint64_t)c->B * sel.N;
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
+    XPNG_REQUIRE(c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_sums, c->d_tile_sz, c->d_off,
+                 c->d_totals, c->h_total);
     HIPCHK(hipMemsetAsync(c->d_flags2, 0, VN * 4, s));
     HIPCHK(hipMemsetAsync(c->d_stream_n2, 0, VN * M2_SLOTS * 4, s));
     HIPCHK(hipMemsetAsync(c->d_blk2, 0, VN * M2_SLOTS * sizeof(M2Blk), s));
     k_m2_classify<<<total * 16, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, 16, c->d_flags2);
-    if (launch_transform<3>(c, nimg, t0, t1, s)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes
-    if ((uint64_t)total * M2_STREAMS > 2048 && !getenv("XPNG_BIG_BLOCKS")) k_m2_streams<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
+    if (launch_transform<3>(c, nimg, t0, t1, s)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes (allocates them on first use)
+    XPNG_REQUIRE(c->d_planes);
+    if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_streams<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     else k_m2_streams<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     const uint32_t gbpt = (max_n + 256 * M2_GRAY_REPS - 1) / (256 * M2_GRAY_REPS);
     k_m2_gray_syms<<<total * gbpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, gbpt, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
@@ -475,6 +502,7 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
                 hipMalloc((void **)&c->d_w1F, VN * M2_SLOTS * 512) != hipSuccess)
                 return fail("hipMalloc failed (mode-2 wide encode workspace)");
         }
+        XPNG_REQUIRE(c->d_w1prep, c->d_w1tab, c->d_w1F);
         k_rans1_prep<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2, c->d_w1prep, c->d_w1tab, c->d_w1F);
         k_rans1_chain<true><<<((total + 15) / 16) * W1_BIG_SLOTS, 64, 0, s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
         k_rans1_chain<false><<<((total + 31) / 32) * W1_SMALL_SLOTS, 64, 0, s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
@@ -533,8 +561,10 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     HIPCHK(hipMemsetAsync(c->d_status, 0, 4, s));
     uint32_t max_w = 0, max_h = 0;
     for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
+    XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles);
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
+        XPNG_REQUIRE(c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2);
         return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off, (uint32_t)t0,
                                 (uint32_t)t1, c->d_dec_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
     }
@@ -561,6 +591,7 @@ extern "C" int xpnghip_ctx_decode_status(xpnghip_ctx *c, void *stream) {
 
 // ---- introspection for parity tests ----------------------------------------------------------------------
 // wave probe (common.hpp): register a device buffer of `cap` WaveProbe records (nullptr: off); the count so far
+#ifdef XPNG_PROBES
 extern "C" int xpnghip_debug_probe(void *d_buf, uint32_t cap) {
     WaveProbe *p = (WaveProbe *)d_buf;
     const uint32_t zero = 0;
@@ -575,6 +606,12 @@ extern "C" int64_t xpnghip_debug_probe_count(void) {
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_probe_n), sizeof(n)) != hipSuccess) return -1;
     return n;
 }
+extern "C" int xpnghip_probes_built(void) { return 1; }
+#else
+extern "C" int xpnghip_debug_probe(void *, uint32_t) { return fail("the wave probe exists only in libxpng_hip_probes.so (make probes)"); }
+extern "C" int64_t xpnghip_debug_probe_count(void) { return -1; }
+extern "C" int xpnghip_probes_built(void) { return 0; }
+#endif
 
 extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, void *out, uint64_t cap) {
     if (!c || tile >= c->tiles.size() || !out) return -1;
@@ -609,6 +646,7 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
         if (!d2h(cn, c->d_ctx_n + tile * 9, 36) || !d2h(tmp, c->d_blk_sz + tile * 10, 40)) return -1;
         src = c->d_scratch + t.sbase + off_blk(t.n, cn, what - 20); bytes = tmp[what - 20];
     } else if (what == 40 || what == 41) {
+        if (!c->d_dbg) return -1;  // phase stamps exist in probe builds only
         src = (const uint8_t *)(c->d_dbg + ((what - 40) * c->tiles.size() * c->B + tile) * 80); bytes = 640;
     } else if (what == 30) {
         src = (const uint8_t *)(c->d_sums + tile * 4); bytes = 16;

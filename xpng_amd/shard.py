@@ -52,18 +52,25 @@ def tile_ranges(n_tiles: int, world: int) -> List[Tuple[int, int]]:
 
 
 def weighted_tile_ranges(tiles: Sequence[Tuple[int, int, int, int]], world: int) -> List[Tuple[int, int]]:
-    """Contiguous ranges balanced by pixel count (first-row / first-column tiles are up to 2.25x larger)."""
+    """Contiguous ranges balanced by pixel count (first-row / first-column tiles are up to 2.25x larger): range k ends at
+    the first tile where the running pixel count reaches k/world of the total, and every range keeps at least one tile
+    while tiles last (ranks beyond the tile count get empty ranges).  The same rule, in the same integer arithmetic, as
+    shard_ranges() in csrc/wrappers.hpp (xpnghip_shard_ranges; tests/test_abi.py cross-checks the two)."""
+    n = len(tiles)
+    d = min(world, n)
     total = sum(t[2] * t[3] for t in tiles)
     out, start, acc, k = [], 0, 0, 1
     for i, t in enumerate(tiles):
+        if k >= d:
+            break
         acc += t[2] * t[3]
-        while k < world and acc >= total * k / world and i + 1 <= len(tiles) - (world - k):
+        if acc * d >= total * k or n - (i + 1) == d - k:
             out.append((start, i + 1))
             start = i + 1
             k += 1
-    out.append((start, len(tiles)))
+    out.append((start, n))
     while len(out) < world:
-        out.append((len(tiles), len(tiles)))
+        out.append((n, n))
     return out
 
 
