@@ -1,0 +1,9 @@
+#!/bin/bash
+# headline leg only (64 rasters x 4 slots), N runs; prints value / ms_per_step / single-image times.  usage: quick_bench.sh [N] [extra bench args]
+n=${1:-2}; shift
+for i in $(seq $n); do
+  python bench.py --no-legs --no-config4 --no-cpu --steps 20 --warmup 5 --roofline-reps 20 "$@" 2>/dev/null | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('value', d['value'], 'ms', d['ms_per_step'], 'roof', d['roofline']['frac'], 'enc1', d['single_image_encode_ms'], 'dec1', d['single_image_decode_ms'], 'api', d['single_image'].get('api_encode_ms'), d['single_image'].get('api_decode_ms'), 'GB', d['config']['hbm_in_use_gb'])"
+done

@@ -78,6 +78,13 @@ inline void dbg_count_sequence() {}
 constexpr bool dbg_skip(const char *) { return false; }
 #endif
 
+// LDS of the serial-chain kernels is DYNAMIC (extern __shared__, size passed at launch), never a static array.  With a static
+// array the compiler knows that 37-51 KB per single-wave workgroup allows at most one such wave per SIMD and then RAISES the
+// kernel's register allocation to the smallest number that enforces exactly that (AMDGPU: NumVGPRsForWavesPerEU = 257 for a
+// kernel that uses 82 - "Occupancy: 1" in the ISA listing): every alpha-chain / walk wave then held 264 of its SIMD's 512
+// registers, no two of them could share a SIMD, and a SIMD that hosted one had room for three transform waves instead of
+// five.  That is the "fat workgroups start 5-15 ms late" of profiles/r02_wave_probe_p4.txt and most of why bandwidth kernels
+// ran 5-8x their solo time beside the chains.  With dynamic LDS the allocation is what the code uses.
 constexpr uint32_t TILE_AREA = 444u * 444u;  // reference libxpng.c:49
 constexpr uint32_t NL_NONE = 0xFFu;          // nl-plane marker: pixel emits no colour symbol
 constexpr int WAVE = 64;

@@ -180,13 +180,16 @@ namespace xpng {
 // MAXPB bounds the slot table (2^MAXPB bytes of LDS): 12 for the nl-context streams, 15 for alpha.  A block whose
 // header asks for more than MAXPB is left to the general (MAXPB = 15) launch (`only_over` selects those).
 // One rANS v2 block, one wavefront (the body of k_rans2_decode and of k_rans2_decode_rest below).
-template <int MAXPB>
+// COARSE = false: no slot table at all - a slot is resolved by a binary search over the cumulative counts.  Slow, but 4.6 KB of
+// LDS instead of 37: the form k_rans2_decode_rest uses (streams the reference never writes; its launch sits on the critical path of
+// every batched decode and used to wait milliseconds for 128 x 37 KB of LDS to find nothing to do).
+template <int MAXPB, bool COARSE = true>
 __device__ __forceinline__ void rans2_decode_stream(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint32_t j, const uint32_t c, int only_over, uint8_t *__restrict__ ctxsym,
                                                     uint8_t *__restrict__ asym, uint64_t *__restrict__ dbg) {
     // per group of 8 slots: (F | cum << 16, symbol) of the symbol owning slot (g << 3): ONE LDS read resolves a slot whose group
     // lies inside one symbol's range (wide symbols: the probable ones), else a short forward scan over fc[] follows
-    __shared__ uint2 coarse[1 << (MAXPB - 3)];
+    __shared__ uint2 coarse[COARSE ? 1 << (MAXPB - 3) : 1];
     __shared__ uint32_t fc[256];
     __shared__ uint32_t Fs[260];
     __shared__ uint32_t wring[512];
@@ -262,7 +265,7 @@ __device__ __forceinline__ void rans2_decode_stream(const DecTile *__restrict__ 
         hot1 = wmax(m2);
     }
     __syncthreads();
-    {   // coarse slot -> symbol: binary search over cum for every 8th slot (N <= 256 -> 8 probes)
+    if (COARSE) {   // coarse slot -> symbol: binary search over cum for every 8th slot (N <= 256 -> 8 probes)
         const uint32_t groups = 1u << (pb - 3);
         for (uint32_t g = lane; g < groups; g += 64) {
             const uint32_t s = g << 3;
@@ -320,9 +323,14 @@ __device__ __forceinline__ void rans2_decode_stream(const DecTile *__restrict__ 
         if (__ballot(!(hit0_ || hit1_)) == 0) {                                                                   \
             F_ = hit0_ ? F0 : F1; off_ = hit0_ ? d0_ : d1_; sym = hit0_ ? sym0 : sym1;                            \
         } else {                                                                                                  \
-            const uint2 cg_ = coarse[slot_ >> 3];                                                                 \
-            sym = cg_.y;                                                                                          \
-            uint32_t e_ = cg_.x;                                                                                  \
+            uint32_t e_;                                                                                          \
+            if (COARSE) { const uint2 cg_ = coarse[slot_ >> 3]; sym = cg_.y; e_ = cg_.x; }                        \
+            else {  /* largest index with cum <= slot */                                                          \
+                uint32_t lo_ = 0, hi_ = N - 1;                                                                    \
+                while (lo_ < hi_) { const uint32_t mid_ = (lo_ + hi_ + 1) >> 1; if ((fc[mid_] >> 16) <= slot_) lo_ = mid_; else hi_ = mid_ - 1; } \
+                while (lo_ > 0 && (fc[lo_] & 0xFFFF) == 0) lo_--;                                                 \
+                sym = lo_; e_ = fc[lo_];                                                                          \
+            }                                                                                                     \
             while (slot_ - (e_ >> 16) >= (e_ & 0xFFFF) && sym + 1 < N) e_ = fc[++sym];  /* to the symbol whose [cum, cum+F) holds the slot */ \
             F_ = e_ & 0xFFFF; off_ = slot_ - (e_ >> 16);                                                          \
         }                                                                                                         \
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(64) void k_rans2_decode_rest(const DecTile *__restr
         while (m) {
             const uint32_t id2 = sgpr(base + (uint32_t)__builtin_ctzll(m));
             m &= m - 1;
-            rans2_decode_stream<MAXPB>(info, tiles, sel, id2 / c_count, c_first + id2 % c_count, 2, ctxsym, asym, dbg);
+            rans2_decode_stream<MAXPB, false>(info, tiles, sel, id2 / c_count, c_first + id2 % c_count, 2, ctxsym, asym, dbg);
             __syncthreads();
         }
     }
@@ -834,14 +842,17 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 // the previous step are forwarded instead.  Queue 9 is a parking queue that returns 9 forever: a lane whose tile is
 // finished walks it.  Global memory is touched only at 16-step block boundaries: aligned 16-byte chunks are requested for a
 // queue at one service and land in its window at the next (the chunk starts are 16-byte aligned, k_dec_parse).
+constexpr size_t WALK_WIDE_LDS_BYTES = 10 * 64 * 16 + 10 * 16 * 64 * 4;  // heads + windows (k_dec_walk_wide)
 __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
                                                       uint8_t *__restrict__ nlseq, uint32_t j0) {
-    __shared__ u32x4_t head[10 * 64];
     // window: WCH chunks of 16 B per queue; a queue is serviced every SVC-th block.  (8 chunks / every 4th block is ~8 % faster
     // alone, but 90 KB of LDS per wave instead of 50 costs the kernels beside it more than that.)
     constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;
-    __shared__ uint32_t ringw[10 * WDW * 64];
+    static_assert(WALK_WIDE_LDS_BYTES == 10 * 64 * 16 + 10 * WDW * 64 * 4, "LDS layout");
+    extern __shared__ __align__(16) uint8_t walk_wide_lds[];  // dynamic (common.hpp: why)
+    u32x4_t *const head = reinterpret_cast<u32x4_t *>(walk_wide_lds);                        // [10 * 64]
+    uint32_t *const ringw = reinterpret_cast<uint32_t *>(walk_wide_lds + 10 * 64 * 16);     // [10 * WDW * 64]
     __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * 64 + lane;  // work items [j0, total_tiles)
@@ -1419,6 +1430,12 @@ __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict
     recon_band_core<PXSZ>(t, dst, bpr, resid + t.pbase, first, (int)((type >> 1) & 1), rb_lds, seam, dbgflags);
 }
 
+// (Round 3 built the residual extraction INTO this kernel - a lane cutting its row's residuals out of k from per-row cursors,
+// no residual plane, no k_dec_resid - and measured it: bit-exact, 13.3 instead of 15.7 ms of kernel time per step, the same
+// 37-38 Gpx/s, and 66.7 instead of 46.3 B/px of HBM traffic (profiles/r03_pmc_step_mem_fold_experiment.json): 64 rows x three
+// variable-rate streams per wave cannot be fetched in whole 64-byte sectors without ~32 KB of LDS rings per wave, and anything less
+// re-fetches every sector once per block because L2 does not keep it for the microsecond between two blocks.  k_dec_resid reads
+// the same streams in raster order, perfectly coalesced; the 4 B/px residual plane is the price of that.  Not kept)
 // --------------------------------------------------------------------------------------------------
 // The serial size walk of the reference decoder (libxpng.c:982: t[i].f = r.p + x; x += low24(first u32)) for a caller whose
 // blobs already live in HBM: one lane per image, cnt dependent loads.  The reference trusts the sizes; here a size that is
@@ -1529,7 +1546,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // rANS blocks, then the serial context walk) are independent until k_dec_resid: run them on two HIP streams.
     if (pxsz == 4) {
         if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) return bad("fork failed");
-        if (wide && !probe_env("XPNG_NARROW_ALPHA")) { if (!dbg_skip("dec_chain_a")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, pad_ch, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym); }
+        if (wide && !probe_env("XPNG_NARROW_ALPHA")) { if (!dbg_skip("dec_chain_a")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, DecChainLds<true, WD_ALPHA_STREAMS>::BYTES + pad_ch, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym); }
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
         const size_t pad_al = probe_pad("XPNG_PAD_AL");
         if (dbg_skip("dec_alpha")) {} else if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
@@ -1537,9 +1554,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
     if (wide) {
-        if (!dbg_skip("dec_chain_c")) k_rans2_dec_chain<false, WD_CTX_STREAMS, false><<<groups * 9, 64, pad_ch, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
+        if (!dbg_skip("dec_chain_c")) k_rans2_dec_chain<false, WD_CTX_STREAMS, false><<<groups * 9, 64, DecChainLds<false, WD_CTX_STREAMS>::BYTES + pad_ch, s>>>(ws.d_info, total, 0, 9, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym);
         // context streams the small layout cannot hold (PROB_BITS > 12 or more than 16 symbols: never written by the reference)
         if (!dbg_skip("dec_odd")) k_rans2_decode_rest<15><<<128, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, 0, 9, ws.d_ctxsym, ws.d_asym, dbg, ws.d_wdec);
+        // (k_rans2_decode_rest resolves slots by binary search: 4.6 KB of LDS, so its 128 workgroups are placed at once - with the
+        //  37 KB slot table of k_rans2_decode<15> they waited up to 5 ms, between the chains and the walk, to find nothing to do)
     } else {
         k_rans2_decode<12><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 0, ws.d_ctxsym, ws.d_asym, dbg);
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
@@ -1571,11 +1590,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                 return bad("stream/event creation failed");
         }
         if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
-        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + 63) / 64, 64, pad_ch, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES + pad_ch, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
-        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
         else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
@@ -1586,11 +1605,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
             k_dec_recon_band<3><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
-    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, 0, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
+    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
+    if (pxsz == 4 && hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
     if (pxsz == 4) {
-        if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (dbg_skip("resid_big")) {} else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);

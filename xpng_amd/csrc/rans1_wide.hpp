@@ -66,14 +66,18 @@ __global__ __launch_bounds__(64) void k_rans1_prep(const TileDesc *__restrict__ 
 }
 
 // BIG: slots 15..20 (tables of 2-4 KB), 16 tiles per wave (32 lanes); else slots 0..14 (tables <= 1 KB), 32 tiles per wave.
+template <bool BIG> constexpr uint32_t rans1_chain_ltab_bytes() { return (BIG ? 16u : 32u) * ((BIG ? 4096u : 1024u) + 16u); }
+template <bool BIG> constexpr size_t rans1_chain_lds_bytes() { return rans1_chain_ltab_bytes<BIG>() + (BIG ? 16u : 32u) * 32u * 4u; }  // dynamic LDS (common.hpp: why dynamic)
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                     uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
                                                     const uint32_t *__restrict__ stream_n, W1Prep *__restrict__ prep,
                                                     const uint8_t *__restrict__ wtab) {
     constexpr uint32_t TPW = BIG ? 16 : 32, TAB = BIG ? 4096 : 1024, TSTRIDE = TAB + 16, NSLOT = BIG ? W1_BIG_SLOTS : W1_SMALL_SLOTS;
-    __shared__ __align__(16) uint8_t ltab[TPW * TSTRIDE];
-    __shared__ __align__(16) uint32_t wbuf[TPW * 32];  // per stream: 16 staged words + 16 nobody reads
+    static_assert(TPW * TSTRIDE == rans1_chain_ltab_bytes<BIG>() && (TPW * TSTRIDE) % 16 == 0, "LDS layout");
+    extern __shared__ __align__(16) uint8_t rans1_chain_lds[];
+    uint8_t *const ltab = rans1_chain_lds;                                                  // [TPW * TSTRIDE]
+    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(rans1_chain_lds + TPW * TSTRIDE);   // [TPW * 32] per stream: 16 staged words + 16 nobody reads
     __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t slot = (BIG ? 15u : 0u) + blockIdx.x % NSLOT, grp = blockIdx.x / NSLOT;

@@ -124,6 +124,12 @@ __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restri
     }
 }
 
+template <bool BIG> struct Dec1ChainLds {  // dynamic LDS layout of one launch (common.hpp: why dynamic)
+    typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
+    static constexpr uint32_t STREAMS = 32, TSTRIDE = L::TAB + 4, RSTRIDE = 4 * L::RING + 4;
+    static constexpr uint32_t OFF_RING = (STREAMS * TSTRIDE + 15u) & ~15u, OFF_OBUF = (OFF_RING + STREAMS * RSTRIDE + 31u) & ~31u;
+    static constexpr size_t BYTES = OFF_OBUF + STREAMS * 32;
+};
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restrict__ info, uint32_t total, const WDec *__restrict__ wdec,
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ scratch2) {
@@ -132,9 +138,12 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     constexpr uint32_t TSTRIDE = TAB + 4;
     constexpr uint32_t PER = RING / 8;            // words one lane requests per boundary
     constexpr uint32_t RSTRIDE = 4 * RING + 4;    // per stream: [RING words][mirror of word 0]
-    __shared__ __align__(16) uint8_t ltab[STREAMS * TSTRIDE];
-    __shared__ __align__(16) uint8_t ring[STREAMS * RSTRIDE];
-    __shared__ __align__(32) uint8_t obuf[STREAMS * 32];
+    typedef Dec1ChainLds<BIG> LD;
+    static_assert(LD::TSTRIDE == TSTRIDE && LD::RSTRIDE == RSTRIDE && LD::STREAMS == STREAMS, "LDS layout");
+    extern __shared__ __align__(32) uint8_t dec1_chain_lds[];
+    uint8_t *const ltab = dec1_chain_lds;                 // [STREAMS * TSTRIDE]
+    uint8_t *const ring = dec1_chain_lds + LD::OFF_RING;  // [STREAMS * RSTRIDE]
+    uint8_t *const obuf = dec1_chain_lds + LD::OFF_OBUF;  // [STREAMS * 32]
     __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t slot = BIG ? W1D_BIG_SLOT[blockIdx.x % NSLOT] : W1D_SMALL_SLOT[blockIdx.x % NSLOT], grp = blockIdx.x / NSLOT;
@@ -308,9 +317,9 @@ inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t t
             hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess) { err = "stream/event creation failed"; return 1; }
     }
     if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) { err = "fork failed"; return 1; }
-    k_rans1_dec_chain<true><<<groups * 7, 64, 0, ws.side>>>(d_info2, total, ws.d_wdec2, ws.d_dtab2, d_scratch2);
+    k_rans1_dec_chain<true><<<groups * 7, 64, Dec1ChainLds<true>::BYTES, ws.side>>>(d_info2, total, ws.d_wdec2, ws.d_dtab2, d_scratch2);
     if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) { err = "join record failed"; return 1; }
-    k_rans1_dec_chain<false><<<groups * 11, 64, 0, s>>>(d_info2, total, ws.d_wdec2, ws.d_dtab2, d_scratch2);
+    k_rans1_dec_chain<false><<<groups * 11, 64, Dec1ChainLds<false>::BYTES, s>>>(d_info2, total, ws.d_wdec2, ws.d_dtab2, d_scratch2);
     if (hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) { err = "join failed"; return 1; }
     return 0;
 }

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
 // So no s_waitcnt for a global access sits in the dependent chain (a conditional store per step does exactly that on
 // gfx9, where stores count on vmcnt).
 typedef uint32_t u32x4_enc __attribute__((ext_vector_type(4)));
+template <bool BIG> constexpr uint32_t chain2_ltab_bytes() { return 32u * ((BIG ? WTC_BYTES : 144u) + 16u); }
+template <bool BIG> constexpr size_t chain2_lds_bytes() { return chain2_ltab_bytes<BIG>() + 32u * 32u * 4u; }  // dynamic LDS of one launch (common.hpp: why dynamic)
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
@@ -108,8 +110,10 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     constexpr uint32_t TSTRIDE = TAB + 16;        // +4 banks per table: lanes mostly look up the same symbol
     constexpr uint32_t SH = BIG ? 1 : 0;          // byte phase of the symbols inside 16-byte chunks (alpha symbol of pixel i is plane byte i)
     constexpr int PB = BIG ? 15 : 12;
-    __shared__ __align__(16) uint8_t ltab[TPW * TSTRIDE];
-    __shared__ __align__(16) uint32_t wbuf[TPW * 32];  // per stream: 16 staged words + 16 nobody reads
+    static_assert(TPW * TSTRIDE == chain2_ltab_bytes<BIG>() && (TPW * TSTRIDE) % 16 == 0, "LDS layout");
+    extern __shared__ __align__(16) uint8_t chain2_lds[];
+    uint8_t *const ltab = chain2_lds;                                                      // [TPW * TSTRIDE]
+    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(chain2_lds + TPW * TSTRIDE);       // [TPW * 32] per stream: 16 staged words + 16 nobody reads
     __builtin_amdgcn_s_setprio(3);
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;

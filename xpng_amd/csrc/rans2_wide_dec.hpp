@@ -215,6 +215,12 @@ typedef __attribute__((address_space(3))) u32x4_t lds128;
 // and a step in which EVERY lane of the wave lands in one of them skips both table reads (which is most steps when the
 // streams are skewed and the wave carries few of them: alpha runs 8 streams per wave for that reason, trading lanes for
 // latency on the longest chain of the decode).
+template <bool BIG, int STREAMS> struct DecChainLds {  // dynamic LDS layout of one launch (common.hpp: why dynamic)
+    typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
+    static constexpr uint32_t LTAB = BIG ? L::TAB : L::CO_OFF, TSTRIDE = LTAB + 4, RSTRIDE = 4 * L::RING + 4;
+    static constexpr uint32_t OFF_RING = (STREAMS * TSTRIDE + 15u) & ~15u, OFF_OBUF = (OFF_RING + STREAMS * RSTRIDE + 31u) & ~31u;
+    static constexpr size_t BYTES = OFF_OBUF + (STREAMS + 1) * 32;
+};
 template <bool BIG, int STREAMS, bool HOT>
 __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restrict__ info, uint32_t total, uint32_t c_first,
                                                         uint32_t c_count, const WDec *__restrict__ wdec,
@@ -231,9 +237,12 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     constexpr uint32_t PER = WD_RING / 8;      // words one lane requests per boundary (the pair: a quarter of the ring)
     constexpr uint32_t RSTRIDE = 4 * WD_RING + 4;  // per stream: [mirror of the last ring word][WD_RING words]
     constexpr uint32_t WD_STREAMS = STREAMS;
-    __shared__ __align__(16) uint8_t ltab[WD_STREAMS * TSTRIDE];
-    __shared__ __align__(16) uint8_t ring[WD_STREAMS * RSTRIDE];
-    __shared__ __align__(32) uint8_t obuf[(WD_STREAMS + 1) * 32];  // per stream: 16 symbol bytes of the block + 16 bytes nobody reads; the last slot belongs to the lanes without a stream (STREAMS < 32)
+    typedef DecChainLds<BIG, STREAMS> LD;
+    static_assert(LD::TSTRIDE == TSTRIDE && LD::RSTRIDE == RSTRIDE, "LDS layout");
+    extern __shared__ __align__(32) uint8_t dec_chain_lds[];
+    uint8_t *const ltab = dec_chain_lds;                 // [WD_STREAMS * TSTRIDE]
+    uint8_t *const ring = dec_chain_lds + LD::OFF_RING;  // [WD_STREAMS * RSTRIDE]
+    uint8_t *const obuf = dec_chain_lds + LD::OFF_OBUF;  // [(WD_STREAMS + 1) * 32] per stream: 16 symbol bytes of the block + 16 bytes nobody reads; the last slot belongs to the lanes without a stream (STREAMS < 32)
     const uint32_t lane = threadIdx.x & 63, kraw = lane >> 1, k = kraw < WD_STREAMS ? kraw : 0, par = lane & 1;  // (idle lanes alias stream 0's LDS harmlessly)
     const uint32_t c = c_first + blockIdx.x % c_count, grp = blockIdx.x / c_count;
     const uint32_t j = grp * WD_STREAMS + kraw;

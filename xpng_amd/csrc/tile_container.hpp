@@ -61,7 +61,8 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < cnt; i0 += 1024) {
+    const uint32_t nt = blockDim.x;  // (256 in the launches: a 1024-thread workgroup needs 16 free wave slots on one CU at once and waited up to 5 ms for them beside the chain kernels of other pipeline slots - on the critical path between the last rANS block and the gather)
+    for (uint32_t i0 = 0; i0 < cnt; i0 += nt) {
         const uint32_t i = i0 + tid;
         const uint64_t v = i < cnt ? tile_sz[i] : 0;
         uint64_t incl = v;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(const uint32_t *__restric
         for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave[w2];
         if (i < cnt) off[i] = base + incl - v;
         __syncthreads();
-        if (tid == 1023) s_base = base + incl;
+        if (tid == nt - 1) s_base = base + incl;
         __syncthreads();
     }
     if (tid == 0) { off[cnt] = s_base; totals[blockIdx.x] = s_base; }

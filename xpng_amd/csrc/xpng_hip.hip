@@ -408,7 +408,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     }
     auto alpha_branch = [&](hipStream_t as) -> int {  // alpha plane -> tables -> chains, on the side stream
         if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
         return 0;
     };
@@ -445,12 +445,12 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
         if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
         if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
         if (!dbg_skip("finish")) k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
-    k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
+    k_tile_offsets<<<nimg, 256, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
     if (!dbg_skip("gather")) k_tile_gather<<<total, 256, pad_ga, s>>>(c->d_in_ptrs, bpr, PXSZ, c->d_tiles, sel, c->spt, c->d_scratch, c->d_k_n, c->d_ctx_n, c->d_blk_sz, c->d_tile_hdr, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
@@ -504,13 +504,13 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         }
         XPNG_REQUIRE(c->d_w1prep, c->d_w1tab, c->d_w1F);
         k_rans1_prep<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2, c->d_w1prep, c->d_w1tab, c->d_w1F);
-        k_rans1_chain<true><<<((total + 15) / 16) * W1_BIG_SLOTS, 64, 0, s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
-        k_rans1_chain<false><<<((total + 31) / 32) * W1_SMALL_SLOTS, 64, 0, s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
+        k_rans1_chain<true><<<((total + 15) / 16) * W1_BIG_SLOTS, 64, rans1_chain_lds_bytes<true>(), s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
+        k_rans1_chain<false><<<((total + 31) / 32) * W1_SMALL_SLOTS, 64, rans1_chain_lds_bytes<false>(), s>>>(c->d_tiles, sel, total, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_w1prep, c->d_w1tab);
         k_rans1_finish<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2, c->d_w1prep, c->d_w1F);
     }
     k_m2_select<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, c->d_flags2, c->d_blk2, c->d_mt2, c->d_tile_sz);
     k_m2_bits<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2);
-    k_tile_offsets<<<nimg, 1024, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
+    k_tile_offsets<<<nimg, 256, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
     k_m2_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_sums, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_total, c->d_totals, (uint64_t)nimg * 8, hipMemcpyDeviceToHost, s));
