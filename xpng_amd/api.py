@@ -191,21 +191,42 @@ _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
 
 
-def encode_tiles(mode: int, raster: np.ndarray, T: int = 1, lib=None) -> bytes:
-    """Host raster (h, w, 3|4) uint8 -> concatenated tile blobs (xpnghip_encode_tiles_T; H2D + kernels + D2H) on T devices."""
+class MallocedBlobs:
+    """The malloc()ed buffer xpnghip_encode_tiles hands back, not yet copied into a Python object (bench.py times the C call
+    alone: the copy into `bytes` and the free() are this binding's, not the library's)."""
+    def __init__(self, p, n):
+        self.p, self.n = p, n
+
+    def bytes(self) -> bytes:
+        return C.string_at(self.p, self.n)
+
+    def free(self):
+        if self.p:
+            _libc.free(self.p)
+            self.p = None
+
+
+def encode_tiles(mode: int, raster: np.ndarray, T: int = 1, lib=None, copy: bool = True):
+    """Host raster (h, w, 3|4) uint8 -> concatenated tile blobs (xpnghip_encode_tiles_T; H2D + kernels + D2H) on T devices.
+    copy=False returns the library's malloc()ed buffer as a MallocedBlobs (caller frees)."""
     raster = np.ascontiguousarray(raster, dtype=np.uint8)
     h, w, ch = raster.shape
     p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
     lib = lib or hip_lib()
     if lib.xpnghip_encode_tiles_T(T, mode, raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(p), C.byref(n)):
         raise XpngError("xpnghip_encode_tiles: " + lib.xpnghip_last_error().decode(errors="replace"))
+    if not copy:
+        return MallocedBlobs(p, n.value)
     out = C.string_at(p, n.value)
     _libc.free(p)
     return out
 
 
-def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int, T: int = 1, lib=None) -> np.ndarray:
-    raster = np.zeros((h, w, pxsz), dtype=np.uint8)
+def decode_tiles(mode: int, blobs: bytes, w: int, h: int, pxsz: int, T: int = 1, lib=None, out: np.ndarray = None) -> np.ndarray:
+    """Tile blobs -> raster (xpnghip_decode_tiles_T).  out: a caller-allocated (h, w, pxsz) uint8 array to fill (what xpng_load's
+    malloc is to the C call, libxpng.c:974); default: a fresh zero-filled one."""
+    raster = np.zeros((h, w, pxsz), dtype=np.uint8) if out is None else out
+    assert raster.shape == (h, w, pxsz) and raster.dtype == np.uint8 and raster.flags["C_CONTIGUOUS"]
     buf = np.frombuffer(blobs, dtype=np.uint8)
     lib = lib or hip_lib()
     if lib.xpnghip_decode_tiles_T(T, mode, buf.ctypes.data_as(C.c_void_p), len(blobs), w, h, pxsz,

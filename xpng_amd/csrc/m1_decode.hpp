@@ -387,12 +387,15 @@ __device__ __forceinline__ void rans2_decode_stream(const DecTile *__restrict__ 
         uint32_t acc = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
+            // (tried in round 3: the step first computed as if both states sat in a hot symbol and needed no refill, ONE ballot of
+            //  "cold symbol OR refill" guarding the general path - 16.4 -> 16.7 ms on the 4096^2 image: on this alpha stream the pair
+            //  is in the general path more than half of the steps, and those then pay the speculative work on top)
             uint32_t sym = 0;
             bool need;
             XPNG_DEC_ONE(sym, need);
-            acc = (acc << 8) | sym;
             const uint32_t m = sgpr((uint32_t)__ballot(need) & 3u);
             if (m) XPNG_DEC_RENORM(need, m);
+            acc = (acc << 8) | sym;
         }
         i -= 8;
         const uint32_t oth = swap_pair(acc);
@@ -1410,24 +1413,27 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
 template <int PXSZ>
 __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                        TileSel sel, const uint32_t *__restrict__ resid,
-                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0) {
+                                                       uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0, uint32_t j1) {
     extern __shared__ uint32_t rb_lds[];  // the lanes' staging rings, then one row of the widest tile of the launch (bottom row of the band above)
     uint32_t *seam = rb_lds + RB_STAGE_WORDS;
-    const uint32_t j = j0 + blockIdx.x, lane = threadIdx.x & 63;
-    const DecTile *d = info + j;
-    const uint32_t type = d->type;
-    if (type == TILE_BAD) return;
-    const TileDesc t = tiles[vtile(sel, j)];
-    uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
-    if (type == 0) {  // raw rows (libxpng.c:846)
-        const uint8_t *src = d->blob + 4;
-        const uint64_t row = (uint64_t)t.w * PXSZ;
-        for (uint64_t b = lane; b < row * t.h; b += 64) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
-        return;
+    const uint32_t lane = threadIdx.x & 63;
+    // work items [j0, j1), one wave each; a launch with fewer workgroups than items walks them with a grid stride (recon_grid)
+    for (uint32_t j = j0 + blockIdx.x; j < j1; j += gridDim.x) {
+        const DecTile *d = info + j;
+        const uint32_t type = d->type;
+        if (type == TILE_BAD) continue;
+        const TileDesc t = tiles[vtile(sel, j)];
+        uint8_t *dst = rasters[t.img] + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
+        if (type == 0) {  // raw rows (libxpng.c:846)
+            const uint8_t *src = d->blob + 4;
+            const uint64_t row = (uint64_t)t.w * PXSZ;
+            for (uint64_t b = lane; b < row * t.h; b += 64) { const uint64_t y = b / row, o = b - y * row; dst[y * bpr + o] = src[b]; }
+            continue;
+        }
+        const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
+        const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | (PXSZ == 4 ? (kw0 & 255u) << 24 : 0u);
+        recon_band_core<PXSZ>(t, dst, bpr, resid + t.pbase, first, (int)((type >> 1) & 1), rb_lds, seam, dbgflags);
     }
-    const uint32_t kw0 = ld32u(d->blob + 8);  // first pixel from the head of k (libxpng.c:850): bytes MSB-first
-    const uint32_t first = ((kw0 >> 24) & 255u) | (((kw0 >> 16) & 255u) << 8) | (((kw0 >> 8) & 255u) << 16) | (PXSZ == 4 ? (kw0 & 255u) << 24 : 0u);
-    recon_band_core<PXSZ>(t, dst, bpr, resid + t.pbase, first, (int)((type >> 1) & 1), rb_lds, seam, dbgflags);
 }
 
 // (Round 3 built the residual extraction INTO this kernel - a lane cutting its row's residuals out of k from per-row cursors,
@@ -1509,6 +1515,13 @@ inline void recon_geometry(uint32_t max_w, uint32_t max_h, uint32_t &free_ew, ui
     free_ew = 0; threads = 1024; lds = 0;
     if (probe_env("XPNG_BARRIER_RECON") || max_h > 1024 || (uint64_t)nw * max_w * 4 + 64 > 60000) return;
     free_ew = max_w; threads = nw * 64; lds = nw * max_w * 4 + 64;
+}
+
+// workgroups of a band-reconstruction launch over n work items (probe builds: XPNG_RECON_CAP)
+inline uint32_t recon_grid(uint32_t n) {
+    const char *e = probe_env("XPNG_RECON_CAP");
+    const uint32_t cap = e ? (uint32_t)atoi(e) : 0u;
+    return cap && cap < n ? cap : n;
 }
 
 inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
@@ -1599,10 +1612,10 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
             if (!dbg_skip("resid_small")) k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            if (!dbg_skip("recon_small")) k_dec_recon_band<4><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb);
+            if (!dbg_skip("recon_small")) k_dec_recon_band<4><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb, total);
         } else {
             k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<3><<<total - jb, 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb);
+            k_dec_recon_band<3><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb, total);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
     } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
@@ -1612,13 +1625,13 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     if (pxsz == 4) {
         if (dbg_skip("resid_big")) {} else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0);
+        if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0, nt);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
         if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
         else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<3><<<nt, 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0);
+        if (band) k_dec_recon_band<3><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0, nt);
         else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }

@@ -33,6 +33,15 @@ static int usable_devices() {
 }
 static int shard_device(int k) { return fake_devices() > 0 ? base_device() : base_device() + k; }
 
+// (probe builds) XPNG_TRACE_API=1: wall-clock marks of the host-buffer calls on stderr
+struct ApiTrace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    ApiTrace() : on(probe_env("XPNG_TRACE_API") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what, int k = -1) const {
+        if (on) fprintf(stderr, "[xpng api] %8.3f ms  %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what, k);
+    }
+};
+
 struct DevGuard {  // pins the work to our devices and hands the caller's current device back
     int prev = -1;
     DevGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
@@ -164,6 +173,33 @@ static std::vector<Shard> make_shards(const std::vector<TileDesc> &tiles, int D)
     }
     return out;
 }
+// ONE device, one ordinary image (the narrow regime: at most 2048 (tile, stream) pairs): the call is cut into tile-row groups
+// that run on the SAME device, each on a context and stream of its own, so that transfers and kernels of one call overlap
+// (6.1 of the 22.5 ms of a 4096^2 decode call were copies):
+//   encode - group 0 is the first tile row: it holds the biggest tile, whose alpha chain is the critical path of the call, and
+//            its band is the first 13 % of the raster, so that chain starts 0.4 ms into the call instead of 2.4;
+//   decode - the groups without the biggest tile finish ~3 ms earlier and their bands (87 % of the raster) travel to the host
+//            while the first row's chains are still running; bands of whole tile rows are contiguous: one 1-D copy each.
+// The bytes are those of the unsplit call (tiles are coded independently; the same code path as T > 1 devices).
+static bool pipeline_shards(const std::vector<TileDesc> &tiles, int pxsz, uint64_t raster_bytes, int dev, std::vector<Shard> &out) {
+    out.clear();
+    const uint64_t N = tiles.size();
+    if (N * (pxsz == 4 ? 10 : 9) > 2048 || raster_bytes < (24u << 20) || probe_env("XPNG_NO_PIPELINE_SHARDS")) return false;
+    std::vector<uint64_t> row_start;  // first tile of every tile row
+    for (uint64_t i = 0; i < N; i++) if (i == 0 || tiles[i].y != tiles[i - 1].y) row_start.push_back(i);
+    const uint64_t R = row_start.size();
+    if (R < 3) return false;
+    row_start.push_back(N);
+    const uint64_t mid = 1 + (R - 1) / 2;  // rows [1, mid) and [mid, R)
+    const uint64_t cuts[4] = {0, 1, mid, R};
+    for (int k = 0; k < 3; k++) {
+        Shard sh{dev, row_start[cuts[k]], row_start[cuts[k + 1]], 0, 0, nullptr, 0, 0};
+        sh.y0 = tiles[sh.r0].y; sh.y1 = tiles[sh.r1 - 1].y + tiles[sh.r1 - 1].h;
+        out.push_back(sh);
+    }
+    return true;
+}
+
 // host-only (no device needed): the tile ranges a call on D devices would use, for the CPU tests that cross-check this
 // split against xpng_amd/shard.py; ranges[2k], ranges[2k+1] = [r0, r1) of device k.  Returns the number of ranges.
 extern "C" int xpnghip_shard_ranges(uint64_t w, uint64_t h, int D, uint64_t *ranges, int cap) {
@@ -221,13 +257,58 @@ static int check_geometry(uint64_t w, uint64_t h, int pxsz) {
     return 0;
 }
 
+// Touches the caller's (typically freshly malloc()ed) raster, one write per page, on a few helper threads while the kernels
+// run: its first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.  The
+// raster is the call's output buffer - its contents are undefined until the call returns 0 - so writing zeros early is
+// harmless; if a helper thread cannot be created the pages simply fault during the copy.
+struct Prefault {
+    static constexpr int NT = 4;
+    std::thread th[NT];
+    int started = 0;
+    void start(uint8_t *raster, uint64_t s) {
+        const uint64_t part = ((s / NT) + 4095) & ~4095ull;
+        for (int t = 0; t < NT; t++) {
+            const uint64_t a = std::min<uint64_t>(s, t * part), b = std::min<uint64_t>(s, (t + 1) * part);
+            try { th[t] = std::thread([=] { for (uint64_t o = a; o < b; o += 4096) raster[o] = 0; }); }
+            catch (...) { return; }  // (std::system_error: no more threads - the ones already started are joined below)
+            started = t + 1;
+        }
+    }
+    void join() { for (int t = 0; t < started; t++) if (th[t].joinable()) th[t].join(); started = 0; }
+    ~Prefault() { join(); }  // (a joinable std::thread must never be destroyed: that is std::terminate, past every catch)
+};
+// pinned staging -> the caller's pageable raster on a few helper threads (the runtime's own pageable download moves ~10 GB/s
+// through one thread: 6.7 ms for a 4096^2 RGBA raster; device -> pinned runs at link speed and four copy threads at ~30 GB/s).
+// When a thread cannot be created its part is copied by the caller's thread, at once.
+struct CopyOut {
+    std::vector<std::thread> th;
+    void start(uint8_t *dst, const uint8_t *src, uint64_t n) {
+        constexpr int NT = 4;
+        const uint64_t part = ((n / NT) + 4095) & ~4095ull;
+        for (int t = 0; t < NT; t++) {
+            const uint64_t a = std::min<uint64_t>(n, t * part), b = std::min<uint64_t>(n, (t + 1) * part);
+            if (a == b) continue;
+            try { th.emplace_back([=] { memcpy(dst + a, src + a, b - a); }); }
+            catch (...) { memcpy(dst + a, src + a, b - a); }
+        }
+    }
+    void join() { for (std::thread &t : th) if (t.joinable()) t.join(); th.clear(); }
+    ~CopyOut() { join(); }
+};
+static int ensure_stage(xpnghip_ctx *c, uint64_t need) {
+    if (c->cap_stage >= need && c->h_stage) return 0;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->cap_stage = 0;
+    HIPCHK(hipHostMalloc((void **)&c->h_stage, need));
+    c->cap_stage = need;
+    return 0;
+}
+
 // Encode on D devices.  The raster is either in host memory (h_src) or already staged on the base device (d_src; the caller
 // has synchronised the stream that produced it).
-static int encode_multi(int D, int mode, const uint8_t *h_src, const uint8_t *d_src, uint64_t w, uint64_t h, int pxsz, uint8_t **blobs, uint64_t *blobs_len) {
+static int encode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tiles, int mode, const uint8_t *h_src, const uint8_t *d_src, uint64_t w, uint64_t h, int pxsz, uint8_t **blobs, uint64_t *blobs_len) {
     const uint64_t bpr = w * (uint64_t)pxsz;
-    std::vector<TileDesc> tiles;
-    build_tiles(w, h, tiles);
-    std::vector<Shard> sh = make_shards(tiles, D);
+    const ApiTrace tr;
     std::vector<CtxLease> leases;
     leases.reserve(sh.size());
     const int dev0 = sh[0].dev;
@@ -251,12 +332,14 @@ static int encode_multi(int D, int mode, const uint8_t *h_src, const uint8_t *d_
         else if (s.dev == dev0) HIPCHK(hipMemcpyAsync(bandp, d_src + (uint64_t)s.y0 * bpr, band, hipMemcpyDeviceToDevice, c->stream));
         else HIPCHK(hipMemcpyPeerAsync(bandp, s.dev, d_src + (uint64_t)s.y0 * bpr, dev0, band, c->stream));
         if (xpnghip_encode_device(c, mode, bandp - (uint64_t)s.y0 * bpr, s.r0, s.r1, c->d_blobs, nullptr, nullptr)) return 1;
+        tr.mark("encode launched, shard", (int)k);
     }
     uint64_t total = 0;
     for (Shard &s : sh) {
         HIPCHK(hipSetDevice(s.dev));
         HIPCHK(hipStreamSynchronize(s.c->stream));
         s.len = s.c->h_total[0]; s.off = total; total += s.len;
+        tr.mark("encode done, shard", (int)(&s - &sh[0]));
     }
     // the one exchange of the path (libxpng.c:764-769): blob ranges -> device 0, behind shard 0's own bytes
     for (size_t k = 1; k < sh.size(); k++) {
@@ -266,10 +349,16 @@ static int encode_multi(int D, int mode, const uint8_t *h_src, const uint8_t *d_
         else HIPCHK(hipMemcpyPeerAsync(sh[0].c->d_blobs + s.off, dev0, s.c->d_blobs, s.dev, s.len, s.c->stream));
     }
     for (size_t k = 1; k < sh.size(); k++) { HIPCHK(hipSetDevice(sh[k].dev)); HIPCHK(hipStreamSynchronize(sh[k].c->stream)); }
+    // (a buffer allocated for the raw bound up front and touched by helper threads while the kernels run, plus a pinned staging
+    //  copy, measured SLOWER - 14.2 against 11.5 ms for the call: the helper threads compete with the runtime's pageable upload of
+    //  the later bands for the host's memory bandwidth, and the first shard's chains start late)
     uint8_t *out = (uint8_t *)malloc(total ? total : 1);
     if (!out) return fail("malloc failed");
     HIPCHK(hipSetDevice(dev0));
-    if (hipMemcpy(out, sh[0].c->d_blobs, total, hipMemcpyDeviceToHost) != hipSuccess) { free(out); return fail("blob download failed"); }
+    // (on the shard's own stream: a plain hipMemcpy is a null-stream operation and waits for every blocking stream of the device,
+    //  i.e. for the calls other host threads have in flight)
+    if (hipMemcpyAsync(out, sh[0].c->d_blobs, total, hipMemcpyDeviceToHost, sh[0].c->stream) != hipSuccess || hipStreamSynchronize(sh[0].c->stream) != hipSuccess) { free(out); return fail("blob download failed"); }
+    tr.mark("blobs on the host", 0);
     *blobs = out; *blobs_len = total;
     return 0;
 }
@@ -280,12 +369,18 @@ static int encode_tiles_impl(uint64_t T, int mode, const uint8_t *raster, uint64
     DevGuard guard;
     const uint64_t N = tile_count_for(w, h);
     const int D = devices_for(T, N);
-    if (D > 1) return encode_multi(D, mode, raster, nullptr, w, h, pxsz, blobs, blobs_len);
+    const uint64_t s = w * h * (uint64_t)pxsz;
+    if (D > 1 || s >= (24u << 20)) {
+        std::vector<TileDesc> tiles;
+        build_tiles(w, h, tiles);
+        std::vector<Shard> sh;
+        if (D > 1) return encode_multi(make_shards(tiles, D), tiles, mode, raster, nullptr, w, h, pxsz, blobs, blobs_len);
+        if (pipeline_shards(tiles, pxsz, s, base_device(), sh)) return encode_multi(sh, tiles, mode, raster, nullptr, w, h, pxsz, blobs, blobs_len);
+    }
     HIPCHK(hipSetDevice(base_device()));
     CtxLease lease(ctx_checkout(base_device(), w, h, pxsz));
     xpnghip_ctx *c = lease.c;
     if (!c) return 1;
-    const uint64_t s = w * h * (uint64_t)pxsz;
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blobs, c->cap_blobs, xpnghip_ctx_blob_bound(c, 0, N))) return 1;
     HIPCHK(hipMemcpyAsync(c->d_raster, raster, s, hipMemcpyHostToDevice, c->stream));
     uint64_t len = 0;
@@ -299,11 +394,10 @@ static int encode_tiles_impl(uint64_t T, int mode, const uint8_t *raster, uint64
 
 // Decode on D devices: the host walks the tile sizes (the file is in host memory, libxpng.c:982), every device gets the blob
 // range of its tiles and fills its band; the bands come back as one rectangle per tile row of the range.
-static int decode_multi(int D, int mode, const uint8_t *blobs, const std::vector<uint64_t> &off, uint64_t w, uint64_t h, int pxsz, uint8_t *raster) {
+static int decode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tiles, int mode, const uint8_t *blobs, const std::vector<uint64_t> &off, uint64_t w, uint64_t h, int pxsz, uint8_t *raster,
+                        bool first_last) {
     const uint64_t bpr = w * (uint64_t)pxsz;
-    std::vector<TileDesc> tiles;
-    build_tiles(w, h, tiles);
-    std::vector<Shard> sh = make_shards(tiles, D);
+    const ApiTrace tr;
     std::vector<CtxLease> leases;
     leases.reserve(sh.size());
     std::vector<uint64_t> rel;
@@ -320,14 +414,36 @@ static int decode_multi(int D, int mode, const uint8_t *blobs, const std::vector
         for (uint64_t &o : rel) o -= s.off;
         uint8_t *bandp = c->d_raster + (((uint64_t)s.y0 * bpr) & 15);
         if (xpnghip_decode_device(c, mode, c->d_blob_in, s.len, rel.data(), s.r0, s.r1, bandp - (uint64_t)s.y0 * bpr, nullptr)) return 1;
+        tr.mark("decode launched, shard", (int)(&s - &sh[0]));
     }
+    Prefault pf;
+    CopyOut out;
+    const uint64_t rbytes = bpr * h;
+    if (rbytes >= (32u << 20) && !probe_env("XPNG_NO_PREFAULT")) pf.start(raster, rbytes);
     int rc = 0;
-    for (Shard &s : sh) {
+    // bands come back in the order the shards finish: with pipeline shards the first one (the biggest tile's row) is the last
+    for (size_t q = 0; q < sh.size(); q++) {
+        Shard &s = sh[first_last ? (q + 1) % sh.size() : q];
         HIPCHK(hipSetDevice(s.dev));
         const int st = xpnghip_ctx_decode_status(s.c, nullptr);
+        tr.mark("decode done, shard", (int)(&s - &sh[0]));
+        pf.join();
         if (st == 1) rc = fail("corrupt file: a tile header is inconsistent with the tile table");
         else if (st != 0) rc = fail("decode failed");
         if (rc) continue;
+        const bool whole_rows = tiles[s.r0].x == 0 && tiles[s.r1 - 1].x + tiles[s.r1 - 1].w == w;
+        if (whole_rows) {  // a band of whole tile rows is contiguous in both rasters: one 1-D copy
+            const uint64_t band = (uint64_t)(s.y1 - s.y0) * bpr;
+            const uint8_t *d_band = s.c->d_raster + (((uint64_t)s.y0 * bpr) & 15);
+            if (first_last && band >= (4u << 20) && !ensure_stage(s.c, band)) {
+                // device -> pinned staging at link speed, then helper threads move it into the caller's raster while the next band
+                // (or the last shard's chains) is still on the device
+                if (hipMemcpyAsync(s.c->h_stage, d_band, band, hipMemcpyDeviceToHost, s.c->stream) != hipSuccess || hipStreamSynchronize(s.c->stream) != hipSuccess) { rc = fail("raster download failed"); continue; }
+                tr.mark("band in pinned staging, shard", (int)(&s - &sh[0]));
+                out.start(raster + (uint64_t)s.y0 * bpr, s.c->h_stage, band);
+            } else if (hipMemcpyAsync(raster + (uint64_t)s.y0 * bpr, d_band, band, hipMemcpyDeviceToHost, s.c->stream) != hipSuccess) rc = fail("raster download failed");
+            continue;
+        }
         for (uint64_t i = s.r0; i < s.r1;) {  // tiles i..j-1 share a tile row: one rectangle
             uint64_t j = i + 1;
             while (j < s.r1 && tiles[j].y == tiles[i].y) j++;
@@ -338,29 +454,10 @@ static int decode_multi(int D, int mode, const uint8_t *blobs, const std::vector
         }
     }
     for (Shard &s : sh) { (void)hipSetDevice(s.dev); if (hipStreamSynchronize(s.c->stream) != hipSuccess && !rc) rc = fail("raster download failed"); }
+    out.join();  // (before the leases hand the contexts, and with them the staging buffers, back)
+    tr.mark("raster complete", 0);
     return rc;
 }
-
-// Touches the caller's (typically freshly malloc()ed) raster, one write per page, on a few helper threads while the kernels
-// run: its first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.  The
-// raster is the call's output buffer - its contents are undefined until the call returns 0 - so writing zeros early is
-// harmless; if a helper thread cannot be created the pages simply fault during the copy.
-struct Prefault {
-    static constexpr int NT = 4;
-    std::thread th[NT];
-    int started = 0;
-    void start(uint8_t *raster, uint64_t s) {
-        const uint64_t part = ((s / NT) + 4095) & ~4095ull;
-        for (int t = 0; t < NT; t++) {
-            const uint64_t a = std::min<uint64_t>(s, t * part), b = std::min<uint64_t>(s, (t + 1) * part);
-            try { th[t] = std::thread([=] { for (uint64_t o = a; o < b; o += 4096) raster[o] = 0; }); }
-            catch (...) { return; }  // (std::system_error: no more threads - the ones already started are joined below)
-            started = t + 1;
-        }
-    }
-    void join() { for (int t = 0; t < started; t++) if (th[t].joinable()) th[t].join(); started = 0; }
-    ~Prefault() { join(); }  // (a joinable std::thread must never be destroyed: that is std::terminate, past every catch)
-};
 
 static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_t blobs_len, uint64_t w, uint64_t h, int pxsz, uint8_t *raster) {
     if (!raster || !blobs) return fail("null argument");
@@ -379,12 +476,18 @@ static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_
     off[N] = o;
     DevGuard guard;
     const int D = devices_for(T, N);
-    if (D > 1) return decode_multi(D, mode, blobs, off, w, h, pxsz, raster);
+    const uint64_t s = w * h * (uint64_t)pxsz;
+    if (D > 1 || s >= (24u << 20)) {
+        std::vector<TileDesc> tiles;
+        build_tiles(w, h, tiles);
+        std::vector<Shard> sh;
+        if (D > 1) return decode_multi(make_shards(tiles, D), tiles, mode, blobs, off, w, h, pxsz, raster, false);
+        if (pipeline_shards(tiles, pxsz, s, base_device(), sh)) return decode_multi(sh, tiles, mode, blobs, off, w, h, pxsz, raster, true);
+    }
     HIPCHK(hipSetDevice(base_device()));
     CtxLease lease(ctx_checkout(base_device(), w, h, pxsz));
     xpnghip_ctx *c = lease.c;
     if (!c) return 1;
-    const uint64_t s = w * h * (uint64_t)pxsz;
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blob_in, c->cap_blob_in, blobs_len)) return 1;
     HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream));
     if (xpnghip_decode_device(c, mode, c->d_blob_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr)) return 1;
@@ -583,7 +686,9 @@ static int image_encode_impl(xpnghip_image *im, uint64_t T, int mode, uint8_t **
     const int D = devices_for(T, N);
     if (D > 1) {
         HIPCHK(hipStreamSynchronize(im->stream));  // (the shards' streams read the staged raster)
-        return encode_multi(D, mode, nullptr, im->cur, im->w, im->h, im->pxsz, blobs, blobs_len);
+        std::vector<TileDesc> tiles;
+        build_tiles(im->w, im->h, tiles);
+        return encode_multi(make_shards(tiles, D), tiles, mode, nullptr, im->cur, im->w, im->h, im->pxsz, blobs, blobs_len);
     }
     CtxLease lease(ctx_checkout(im->dev, im->w, im->h, im->pxsz));
     xpnghip_ctx *c = lease.c;

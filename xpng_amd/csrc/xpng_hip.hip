@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -151,6 +152,8 @@ struct xpnghip_ctx {
     // host-buffer wrappers keep their own device raster / blob buffers here (capacities in bytes; grown on demand, never per call)
     uint8_t *d_raster = nullptr, *d_blobs = nullptr, *d_blob_in = nullptr;
     uint64_t cap_raster = 0, cap_blobs = 0, cap_blob_in = 0;
+    uint8_t *h_stage = nullptr;  // pinned host staging of a decoded band (wrappers.hpp: device -> pinned at link speed, pinned -> caller's raster by copy threads)
+    uint64_t cap_stage = 0;
     uint64_t call = 0;  // id of the last host-wrapper call that used this context (wrappers.hpp: never evicted mid-call)
     DecodeWs dec;
 };
@@ -168,6 +171,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (c->ev_enc_join) (void)hipEventDestroy(c->ev_enc_join);
     decode_ws_free(c->dec);
     if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -581,10 +585,13 @@ extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blo
 extern "C" int xpnghip_ctx_decode_status(xpnghip_ctx *c, void *stream) {
     if (!c) return -1;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    uint32_t v = 0;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
-        hipMemcpy(&v, c->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)(v & 1);
+    // (on the call's own stream, into pinned memory: a plain hipMemcpy runs on the null stream, which waits for every blocking
+    //  stream of the device - a caller with several contexts in flight would wait for all of them here, as the pipeline shards of
+    //  xpnghip_decode_tiles did: the two early shards "finished" when the last one did)
+    volatile uint32_t *hv = reinterpret_cast<volatile uint32_t *>(c->h_total + c->B);  // (h_total has 64 spare bytes behind its B entries)
+    if (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync((void *)hv, c->d_status, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return -1;
+    return (int)(*hv & 1);
 }
 
 #include "wrappers.hpp"
