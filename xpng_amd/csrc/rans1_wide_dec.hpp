@@ -225,6 +225,9 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
             sym = *(const lds8 *)(uintptr_t)(a_co + (slot_ >> csh));
             uint32_t e = *(const lds32u *)(uintptr_t)(a_fc + 2 * sym);  // cum[sym] | cum[sym + 1] << 16
             while (slot_ >= (e >> 16)) { sym++; e = *(const lds32u *)(uintptr_t)(a_fc + 2 * sym); }  // cum[N] = 2^pb (and 0x8000 behind it) stops it
+            // (round 3 put k_rans2_dec_chain's packed 8-way compare here - one 16-byte read of the next eight cumulative counts instead
+            //  of this scan - and measured 10.7 against 11.6 Gpx/s on the level-2 leg: the class streams' 32-slot buckets hold one or
+            //  two boundaries, so the scan is short and the compare's fixed cost - a third LDS round trip and ~20 VALU - loses)
             F = (e >> 16) - (e & 0xFFFFu); off = slot_ - (e & 0xFFFFu);
         }
         if (!act) { F = ident; off = slot_; }

@@ -328,16 +328,16 @@ static int encode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
         // kernels address rows absolutely: the band is handed over as if the whole raster were there (only rows [y0, y1) are
         // touched); it starts at the 16-byte phase row y0 has in the whole raster, so the virtual base stays 16-byte aligned
         uint8_t *bandp = c->d_raster + (((uint64_t)s.y0 * bpr) & 15);
-        if (h_src) HIPCHK(hipMemcpyAsync(bandp, h_src + (uint64_t)s.y0 * bpr, band, hipMemcpyHostToDevice, c->stream));
-        else if (s.dev == dev0) HIPCHK(hipMemcpyAsync(bandp, d_src + (uint64_t)s.y0 * bpr, band, hipMemcpyDeviceToDevice, c->stream));
-        else HIPCHK(hipMemcpyPeerAsync(bandp, s.dev, d_src + (uint64_t)s.y0 * bpr, dev0, band, c->stream));
+        if (h_src) HIPCHK(hipMemcpyAsync(bandp, h_src + (uint64_t)s.y0 * bpr, band, hipMemcpyHostToDevice, ctx_stream(c)));
+        else if (s.dev == dev0) HIPCHK(hipMemcpyAsync(bandp, d_src + (uint64_t)s.y0 * bpr, band, hipMemcpyDeviceToDevice, ctx_stream(c)));
+        else HIPCHK(hipMemcpyPeerAsync(bandp, s.dev, d_src + (uint64_t)s.y0 * bpr, dev0, band, ctx_stream(c)));
         if (xpnghip_encode_device(c, mode, bandp - (uint64_t)s.y0 * bpr, s.r0, s.r1, c->d_blobs, nullptr, nullptr)) return 1;
         tr.mark("encode launched, shard", (int)k);
     }
     uint64_t total = 0;
     for (Shard &s : sh) {
         HIPCHK(hipSetDevice(s.dev));
-        HIPCHK(hipStreamSynchronize(s.c->stream));
+        HIPCHK(hipStreamSynchronize(ctx_stream(s.c)));
         s.len = s.c->h_total[0]; s.off = total; total += s.len;
         tr.mark("encode done, shard", (int)(&s - &sh[0]));
     }
@@ -345,10 +345,10 @@ static int encode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
     for (size_t k = 1; k < sh.size(); k++) {
         Shard &s = sh[k];
         HIPCHK(hipSetDevice(s.dev));
-        if (s.dev == dev0) HIPCHK(hipMemcpyAsync(sh[0].c->d_blobs + s.off, s.c->d_blobs, s.len, hipMemcpyDeviceToDevice, s.c->stream));
-        else HIPCHK(hipMemcpyPeerAsync(sh[0].c->d_blobs + s.off, dev0, s.c->d_blobs, s.dev, s.len, s.c->stream));
+        if (s.dev == dev0) HIPCHK(hipMemcpyAsync(sh[0].c->d_blobs + s.off, s.c->d_blobs, s.len, hipMemcpyDeviceToDevice, ctx_stream(s.c)));
+        else HIPCHK(hipMemcpyPeerAsync(sh[0].c->d_blobs + s.off, dev0, s.c->d_blobs, s.dev, s.len, ctx_stream(s.c)));
     }
-    for (size_t k = 1; k < sh.size(); k++) { HIPCHK(hipSetDevice(sh[k].dev)); HIPCHK(hipStreamSynchronize(sh[k].c->stream)); }
+    for (size_t k = 1; k < sh.size(); k++) { HIPCHK(hipSetDevice(sh[k].dev)); HIPCHK(hipStreamSynchronize(ctx_stream(sh[k].c))); }
     // (a buffer allocated for the raw bound up front and touched by helper threads while the kernels run, plus a pinned staging
     //  copy, measured SLOWER - 14.2 against 11.5 ms for the call: the helper threads compete with the runtime's pageable upload of
     //  the later bands for the host's memory bandwidth, and the first shard's chains start late)
@@ -357,7 +357,7 @@ static int encode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
     HIPCHK(hipSetDevice(dev0));
     // (on the shard's own stream: a plain hipMemcpy is a null-stream operation and waits for every blocking stream of the device,
     //  i.e. for the calls other host threads have in flight)
-    if (hipMemcpyAsync(out, sh[0].c->d_blobs, total, hipMemcpyDeviceToHost, sh[0].c->stream) != hipSuccess || hipStreamSynchronize(sh[0].c->stream) != hipSuccess) { free(out); return fail("blob download failed"); }
+    if (hipMemcpyAsync(out, sh[0].c->d_blobs, total, hipMemcpyDeviceToHost, ctx_stream(sh[0].c)) != hipSuccess || hipStreamSynchronize(ctx_stream(sh[0].c)) != hipSuccess) { free(out); return fail("blob download failed"); }
     tr.mark("blobs on the host", 0);
     *blobs = out; *blobs_len = total;
     return 0;
@@ -382,12 +382,12 @@ static int encode_tiles_impl(uint64_t T, int mode, const uint8_t *raster, uint64
     xpnghip_ctx *c = lease.c;
     if (!c) return 1;
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blobs, c->cap_blobs, xpnghip_ctx_blob_bound(c, 0, N))) return 1;
-    HIPCHK(hipMemcpyAsync(c->d_raster, raster, s, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_raster, raster, s, hipMemcpyHostToDevice, ctx_stream(c)));
     uint64_t len = 0;
     if (xpnghip_encode_device(c, mode, c->d_raster, 0, N, c->d_blobs, &len, nullptr)) return 1;
     uint8_t *out = (uint8_t *)malloc(len ? len : 1);
     if (!out) return fail("malloc failed");
-    if (hipMemcpyAsync(out, c->d_blobs, len, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { free(out); return fail("blob download failed"); }
+    if (hipMemcpyAsync(out, c->d_blobs, len, hipMemcpyDeviceToHost, ctx_stream(c)) != hipSuccess || hipStreamSynchronize(ctx_stream(c)) != hipSuccess) { free(out); return fail("blob download failed"); }
     *blobs = out; *blobs_len = len;
     return 0;
 }
@@ -409,7 +409,7 @@ static int decode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
         s.off = off[s.r0]; s.len = off[s.r1] - off[s.r0];
         const uint64_t band = (uint64_t)(s.y1 - s.y0) * bpr;
         if (ensure_buf(c->d_raster, c->cap_raster, band + 16) || ensure_buf(c->d_blob_in, c->cap_blob_in, s.len)) return 1;
-        HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs + s.off, s.len, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs + s.off, s.len, hipMemcpyHostToDevice, ctx_stream(c)));
         rel.assign(off.begin() + (long)s.r0, off.begin() + (long)s.r1);
         for (uint64_t &o : rel) o -= s.off;
         uint8_t *bandp = c->d_raster + (((uint64_t)s.y0 * bpr) & 15);
@@ -438,10 +438,10 @@ static int decode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
             if (first_last && band >= (4u << 20) && !ensure_stage(s.c, band)) {
                 // device -> pinned staging at link speed, then helper threads move it into the caller's raster while the next band
                 // (or the last shard's chains) is still on the device
-                if (hipMemcpyAsync(s.c->h_stage, d_band, band, hipMemcpyDeviceToHost, s.c->stream) != hipSuccess || hipStreamSynchronize(s.c->stream) != hipSuccess) { rc = fail("raster download failed"); continue; }
+                if (hipMemcpyAsync(s.c->h_stage, d_band, band, hipMemcpyDeviceToHost, ctx_stream(s.c)) != hipSuccess || hipStreamSynchronize(ctx_stream(s.c)) != hipSuccess) { rc = fail("raster download failed"); continue; }
                 tr.mark("band in pinned staging, shard", (int)(&s - &sh[0]));
                 out.start(raster + (uint64_t)s.y0 * bpr, s.c->h_stage, band);
-            } else if (hipMemcpyAsync(raster + (uint64_t)s.y0 * bpr, d_band, band, hipMemcpyDeviceToHost, s.c->stream) != hipSuccess) rc = fail("raster download failed");
+            } else if (hipMemcpyAsync(raster + (uint64_t)s.y0 * bpr, d_band, band, hipMemcpyDeviceToHost, ctx_stream(s.c)) != hipSuccess) rc = fail("raster download failed");
             continue;
         }
         for (uint64_t i = s.r0; i < s.r1;) {  // tiles i..j-1 share a tile row: one rectangle
@@ -449,11 +449,11 @@ static int decode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
             while (j < s.r1 && tiles[j].y == tiles[i].y) j++;
             const uint64_t x0 = tiles[i].x, x1 = tiles[j - 1].x + tiles[j - 1].w, y = tiles[i].y;
             if (hipMemcpy2DAsync(raster + y * bpr + x0 * pxsz, bpr, s.c->d_raster + (((uint64_t)s.y0 * bpr) & 15) + (y - s.y0) * bpr + x0 * pxsz, bpr, (x1 - x0) * pxsz, tiles[i].h,
-                                 hipMemcpyDeviceToHost, s.c->stream) != hipSuccess) { rc = fail("raster download failed"); break; }
+                                 hipMemcpyDeviceToHost, ctx_stream(s.c)) != hipSuccess) { rc = fail("raster download failed"); break; }
             i = j;
         }
     }
-    for (Shard &s : sh) { (void)hipSetDevice(s.dev); if (hipStreamSynchronize(s.c->stream) != hipSuccess && !rc) rc = fail("raster download failed"); }
+    for (Shard &s : sh) { (void)hipSetDevice(s.dev); if (hipStreamSynchronize(ctx_stream(s.c)) != hipSuccess && !rc) rc = fail("raster download failed"); }
     out.join();  // (before the leases hand the contexts, and with them the staging buffers, back)
     tr.mark("raster complete", 0);
     return rc;
@@ -489,7 +489,7 @@ static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_
     xpnghip_ctx *c = lease.c;
     if (!c) return 1;
     if (ensure_buf(c->d_raster, c->cap_raster, s) || ensure_buf(c->d_blob_in, c->cap_blob_in, blobs_len)) return 1;
-    HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs, blobs_len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_blob_in, blobs, blobs_len, hipMemcpyHostToDevice, ctx_stream(c)));
     if (xpnghip_decode_device(c, mode, c->d_blob_in, blobs_len, off.data(), 0, N, c->d_raster, nullptr)) return 1;
     Prefault pf;
     if (s >= (32u << 20) && !probe_env("XPNG_NO_PREFAULT")) pf.start(raster, s);
@@ -498,8 +498,8 @@ static int decode_tiles_impl(uint64_t T, int mode, const uint8_t *blobs, uint64_
     if (st == 1) return fail("corrupt file: a tile header is inconsistent with the tile table");
     if (st != 0) return fail("decode failed");
     // (a pinned staging buffer with chunked copies and host copy threads measured no better than this plain copy: 21.8 against 21.5 ms)
-    HIPCHK(hipMemcpyAsync(raster, c->d_raster, s, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(raster, c->d_raster, s, hipMemcpyDeviceToHost, ctx_stream(c)));
+    HIPCHK(hipStreamSynchronize(ctx_stream(c)));
     return 0;
 }
 

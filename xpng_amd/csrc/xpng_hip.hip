@@ -158,6 +158,18 @@ struct xpnghip_ctx {
     DecodeWs dec;
 };
 
+// the context's own stream, created when a call first needs it (the `stream == NULL` form of the device-resident entry points,
+// and the host-buffer wrappers).  On failure nullptr, i.e. the legacy default stream: slower, still correct.
+static hipStream_t ctx_stream(xpnghip_ctx *c) {
+    if (!c->stream) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) c->stream = nullptr;
+        if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+    }
+    return c->stream;
+}
+
 extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -249,7 +261,9 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         for (uint32_t i : ord) if ((uint64_t)c->tiles[i].n * 4 >= (uint64_t)c->tiles[ord[0]].n * 3) c->n_big++;
     }
     c->stamps = c->d_dbg && probe_env("XPNG_STAMPS") != nullptr;  // (probe builds only)
-    if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+    // (c->stream is created on first use, ctx_stream(): a caller that always passes its own stream never needs it, and every
+    //  stream alive takes one of the runtime's hardware queues - with more streams than queues, streams share queues and serialise)
+    if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess ||
         hipMemcpy(c->d_tiles, all.data(), VN * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess) {
         xpnghip_ctx_destroy(c);
         return fail("context setup failed");
@@ -364,7 +378,7 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
 extern "C" int xpnghip_m1_transform_device(xpnghip_ctx *c, const void *d_raster, uint64_t t0, uint64_t t1, void *stream) {
     if (check_range(c, t0, t1)) return 1;
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     void *dummy = c->d_out_ptrs;  // no output buffer in this stage
     if (set_ptrs(c, &d_raster, &dummy, 1, s)) return 1;
     return c->pxsz == 4 ? launch_transform<4>(c, 1, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, 1, (uint32_t)t0, (uint32_t)t1, s);
@@ -373,7 +387,7 @@ extern "C" int xpnghip_m1_transform_device(xpnghip_ctx *c, const void *d_raster,
 extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *const *d_rasters, uint32_t nimg, uint64_t t0, uint64_t t1, void *stream) {
     if (check_range(c, t0, t1)) return 1;
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     std::vector<void *> dummy(nimg, (void *)c->d_out_ptrs);  // no output buffers in this stage
     if (set_ptrs(c, d_rasters, dummy.data(), nimg, s)) return 1;
     return c->pxsz == 4 ? launch_transform<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
@@ -530,7 +544,7 @@ extern "C" int xpnghip_encode_device_batch(xpnghip_ctx *c, int mode, const void 
         for (uint64_t i = t0; i < t1; i++)
             if (c->tiles[i].w < 4 || c->tiles[i].h < 4) return fail("RGBA tile narrower than 4 px: undefined in the reference; store level 7");
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     if (set_ptrs(c, d_rasters, d_blobs, nimg, s)) return 1;
     const int rc = mode == 2 ? launch_encode_m2(c, nimg, (uint32_t)t0, (uint32_t)t1, s)
                    : c->pxsz == 4 ? launch_encode_m1<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_encode_m1<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
@@ -554,7 +568,7 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     if (mode != 1 && mode != 2) return fail("tile mode must be 1 or 2");
     if (mode == 2 && c->pxsz != 3) return fail("mode 2 codes RGB only");
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     if (set_ptrs(c, d_blobs, d_rasters, nimg, s, true)) return 1;
     if (!blobs_len) return fail("blob lengths are required (tile headers are validated against them)");
     if (c->h_blob_len.size() != nimg || memcmp(c->h_blob_len.data(), blobs_len, (size_t)nimg * 8) != 0) {
@@ -584,7 +598,7 @@ extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blo
 // rejected (its pixels were left untouched), -1 = HIP error.
 extern "C" int xpnghip_ctx_decode_status(xpnghip_ctx *c, void *stream) {
     if (!c) return -1;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     // (on the call's own stream, into pinned memory: a plain hipMemcpy runs on the null stream, which waits for every blocking
     //  stream of the device - a caller with several contexts in flight would wait for all of them here, as the pipeline shards of
     //  xpnghip_decode_tiles did: the two early shards "finished" when the last one did)
@@ -622,7 +636,7 @@ extern "C" int xpnghip_probes_built(void) { return 0; }
 
 extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, void *out, uint64_t cap) {
     if (!c || tile >= c->tiles.size() || !out) return -1;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    if (hipSetDevice(c->device) != hipSuccess || (c->stream && hipStreamSynchronize(c->stream) != hipSuccess)) return -1;  // (debug_fetch follows a call that synchronised its stream or used this one)
     const TileDesc &t = c->tiles[tile];
     const uint8_t *src = nullptr;
     uint64_t bytes = 0;
