@@ -111,7 +111,7 @@ struct xpnghip_ctx {
     uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
     TileDesc *d_tiles = nullptr;
     uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (5 symbol planes): allocated on first use (config-2 entry, mode 2, XPNG_UNFUSED)
-    uint8_t *d_aplane = nullptr;        // alpha symbol plane of the fused product path (always there)
+    uint8_t *d_aplane = nullptr;        // alpha symbol plane of the fused form (XPNG_FUSED): allocated on first use
     const uint8_t *alpha_src = nullptr; // where the last encode left its alpha symbols (debug_fetch 5)
     uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
     uint64_t *d_off = nullptr, *d_totals = nullptr, *d_dbg = nullptr;
@@ -224,7 +224,8 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         c->ws_bytes += (bytes);                                                                    \
     } while (0)
     ALLOC(c->d_tiles, VN * sizeof(TileDesc));
-    ALLOC(c->d_aplane, c->plane_stride + 8192);       // + slack: LDS-ring staging reads whole 1 KB units
+    // (d_aplane, the alpha symbol plane of the FUSED form, is allocated on its first use: ensure_aplane - 1 B/px the default form
+    //  never touches, 1.07 GB per 64-image context of 4096^2 rasters)
     ALLOC(c->d_scratch, c->scratch_img * batch + 8192);
     c->dec.arena = c->d_scratch;   // decode keeps its symbol / residual planes in the encode stream scratch (DecodeWs::arena)
     c->dec.arena_bytes = c->scratch_img * batch + 8192;
@@ -323,6 +324,12 @@ static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1)
 }
 
 // the five symbol planes of the unfused form (BASELINE config-2 entry, mode 2, XPNG_UNFUSED): 5 B/px, allocated on first use
+static int ensure_aplane(xpnghip_ctx *c) {
+    if (c->d_aplane) return 0;
+    HIPCHK(hipMalloc((void **)&c->d_aplane, c->plane_stride + 8192));  // + slack: LDS-ring staging reads whole 1 KB units
+    c->ws_bytes += c->plane_stride + 8192;
+    return 0;
+}
 static int ensure_planes(xpnghip_ctx *c) {
     if (c->d_planes) return 0;
     HIPCHK(hipMalloc((void **)&c->d_planes, 5 * c->plane_stride + 8192));
@@ -414,8 +421,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     // the alpha chains start ~5 ms later: measured 16.0 against 13.7 ms per 64 images at 3 slots)
     const bool alpha_pass = fused && PXSZ == 4 && !probe_env("XPNG_ALPHA_IN_FUSED");
     static const size_t pad_tr = probe_pad("XPNG_PAD_TR"), pad_st = probe_pad("XPNG_PAD_ST"), pad_ga = probe_pad("XPNG_PAD_GA");
-    if (!fused && ensure_planes(c)) return 1;  // (before their address is taken below)
-    XPNG_REQUIRE(c->d_aplane, fused ? (const void *)c->d_aplane : (const void *)c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
+    if (fused ? ensure_aplane(c) : ensure_planes(c)) return 1;  // (before their address is taken below)
+    XPNG_REQUIRE(fused ? (const void *)c->d_aplane : (const void *)c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
                  c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->h_total);
     const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
     const bool alpha_side = !narrow && PXSZ == 4;
