@@ -154,6 +154,42 @@ def test_full_size_4096_matches_reference_md5(gpu, manifest, name, level, tmp_pa
     assert np.array_equal(back, raster)
 
 
+def test_pipeline_shards_of_the_host_buffer_calls(gpu, manifest, tmp_path):
+    """An ordinary large image goes through xpnghip_encode_tiles / xpnghip_decode_tiles as three tile-row groups on ONE device
+    (wrappers.hpp pipeline_shards: transfers overlap the chains; the first tile row first, its band the last to come back through
+    pinned staging and copy threads).  Bytes are those of the reference; a corrupt or truncated body is rejected on that path
+    too (a wrong size word in any group), and the raster handed in is complete when the call returns 0."""
+    from xpng_amd import api
+    name = "synth_photo_4096x4096_rgba"
+    ent = manifest[name]
+    raster = golden_raster(name, ent)
+    blobs = api.encode_tiles(1, raster)
+    from xpng_amd.synth import seven_header
+    assert md5(seven_header(4096, 4096, True, level=1) + blobs) == ent["L1"]["md5"]
+    out = np.empty_like(raster)                                  # untouched pages, like xpng_load's malloc
+    api.decode_tiles(1, blobs, 4096, 4096, 4, out=out)
+    assert np.array_equal(out, raster)
+    off, total = api.walk_tile_offsets(blobs, 81)
+    assert total == len(blobs)
+    for t in (0, 8, 9, 40, 80):                                   # a tile of every group, first and last
+        bad = bytearray(blobs)
+        bad[off[t] + 4:off[t] + 8] = b"\xff\xff\xff\x7f"          # k size beyond the tile's blob
+        with pytest.raises(api.XpngError):
+            api.decode_tiles(1, bytes(bad), 4096, 4096, 4)
+    with pytest.raises(api.XpngError):
+        api.decode_tiles(1, blobs[: len(blobs) // 2], 4096, 4096, 4)
+    out2 = np.empty_like(raster)
+    api.decode_tiles(1, blobs, 4096, 4096, 4, out=out2)          # and the path is intact afterwards
+    assert np.array_equal(out2, raster)
+    # RGB, level 2, odd geometry: bands start at every 16-byte phase
+    from xpng_amd.synth import synth_raster
+    from oracle import pyoracle as po
+    r2 = synth_raster("photo", 3001, 2999, False, seed=9)
+    want = po.encode_tiles(2, r2)
+    assert api.encode_tiles(2, r2) == want
+    assert np.array_equal(api.decode_tiles(2, want, 3001, 2999, 3), r2)
+
+
 def test_tile_range_sharding_concatenates_to_whole(gpu, po):
     """Tiles are independent: encoding [0,k) and [k,N) separately and concatenating equals the whole (multi-GPU rule)."""
     import torch

@@ -85,6 +85,10 @@ constexpr bool dbg_skip(const char *) { return false; }
 // registers, no two of them could share a SIMD, and a SIMD that hosted one had room for three transform waves instead of
 // five.  That is the "fat workgroups start 5-15 ms late" of profiles/r02_wave_probe_p4.txt and most of why bandwidth kernels
 // ran 5-8x their solo time beside the chains.  With dynamic LDS the allocation is what the code uses.
+// wave priority of the serial-chain kernels (s_setprio; the throughput kernels run at 0)
+#ifndef XPNG_CHAIN_PRIO
+#define XPNG_CHAIN_PRIO 3
+#endif
 constexpr uint32_t TILE_AREA = 444u * 444u;  // reference libxpng.c:49
 constexpr uint32_t NL_NONE = 0xFFu;          // nl-plane marker: pixel emits no colour symbol
 constexpr int WAVE = 64;

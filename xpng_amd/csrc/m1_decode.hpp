@@ -856,7 +856,7 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     extern __shared__ __align__(16) uint8_t walk_wide_lds[];  // dynamic (common.hpp: why)
     u32x4_t *const head = reinterpret_cast<u32x4_t *>(walk_wide_lds);                        // [10 * 64]
     uint32_t *const ringw = reinterpret_cast<uint32_t *>(walk_wide_lds + 10 * 64 * 16);     // [10 * WDW * 64]
-    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * 64 + lane;  // work items [j0, total_tiles)
     bool live = j < total_tiles;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     extern __shared__ __align__(16) uint8_t rans1_chain_lds[];
     uint8_t *const ltab = rans1_chain_lds;                                                  // [TPW * TSTRIDE]
     uint32_t *const wbuf = reinterpret_cast<uint32_t *>(rans1_chain_lds + TPW * TSTRIDE);   // [TPW * 32] per stream: 16 staged words + 16 nobody reads
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t slot = (BIG ? 15u : 0u) + blockIdx.x % NSLOT, grp = blockIdx.x / NSLOT;
     const uint32_t j = grp * TPW + k;

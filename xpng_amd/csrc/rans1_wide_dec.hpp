@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     uint8_t *const ltab = dec1_chain_lds;                 // [STREAMS * TSTRIDE]
     uint8_t *const ring = dec1_chain_lds + LD::OFF_RING;  // [STREAMS * RSTRIDE]
     uint8_t *const obuf = dec1_chain_lds + LD::OFF_OBUF;  // [STREAMS * 32]
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t slot = BIG ? W1D_BIG_SLOT[blockIdx.x % NSLOT] : W1D_SMALL_SLOT[blockIdx.x % NSLOT], grp = blockIdx.x / NSLOT;
     const uint32_t j = grp * STREAMS + k;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     extern __shared__ __align__(16) uint8_t chain2_lds[];
     uint8_t *const ltab = chain2_lds;                                                      // [TPW * TSTRIDE]
     uint32_t *const wbuf = reinterpret_cast<uint32_t *>(chain2_lds + TPW * TSTRIDE);       // [TPW * 32] per stream: 16 staged words + 16 nobody reads
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t c = BIG ? 9 : blockIdx.x % 9, grp = BIG ? blockIdx.x : blockIdx.x / 9;

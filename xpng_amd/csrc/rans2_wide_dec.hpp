@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
                                                         uint32_t c_count, const WDec *__restrict__ wdec,
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ ctxsym,
                                                         uint8_t *__restrict__ asym) {
-    __builtin_amdgcn_s_setprio(3);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
+    __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     XPNG_PROBE_BEGIN()
     typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
     constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, WD_RING = L::RING, KIND = BIG ? 2 : 1;
