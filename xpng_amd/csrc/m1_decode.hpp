@@ -1302,6 +1302,18 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
         uint8_t *dal = drow - 4 * ao;
         const int32_t olo = active ? ao : 0, ohi = active ? ao + w : 0;  // valid pixel positions of this lane
         const uint32_t pho = (uint32_t)(ao - (int32_t)lane) & 3u;      // every 4-word pixel write of this lane starts at po = pho (mod 4)
+        // RGB [r3]: the same staging in BYTE positions (a pixel is 3 bytes at any alignment): pb = 3 x + ab counts bytes from the
+        // 64-byte boundary in front of the row's first byte; four pixels are one unaligned 12-byte LDS write into the lane's 128-byte
+        // ring (a write that crosses its end continues in the 16-byte spill zone and is taken back when ring chunk 0 is flushed);
+        // a 64-byte chunk leaves as four aligned 16-byte stores once a block (48 bytes) has completed it; only the partial
+        // granules at the two ends of a row fall back to dword / byte stores.  (Round 2 stored every group as 12 bytes at its own
+        // address: 64 rows x 12 bytes per wave instruction.)
+        const int32_t ab = PXSZ == 3 ? (int32_t)((uintptr_t)drow & 63u) : 0;
+        uint8_t *dalb = drow - ab;
+        const int32_t blo = active ? ab : 0, bhi = active ? ab + 3 * w : 0;  // valid byte positions of this lane
+        int32_t pb0 = ab - 3 * (int32_t)lane;                           // byte position of the block's first pixel
+        int32_t flc = pb0 >> 6;                                          // next chunk to flush
+        uint32_t sp_n = 0;                                               // bytes of ring chunk 0 that sit in the spill zone
         const uint32_t S = t.w + 63;
         uint32_t prev = 0, U = 0, ev = 0;
 #define XPNG_RB_CLAMP(c) ((c) < 0 ? 0 : (c) > Lc ? Lc : (c))
@@ -1313,7 +1325,7 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
         XPNG_RB_LOAD(G, p0 >> 4);
         XPNG_RB_PUT(G, p0 >> 4);
         XPNG_RB_LOAD(G, (p0 >> 4) + 1);
-        for (uint32_t s0 = 0; s0 < S; s0 += 16, p0 += 16, po0 += 16) {
+        for (uint32_t s0 = 0; s0 < S; s0 += 16, p0 += 16, po0 += 16, pb0 += 48) {
             // block of 16 steps: the chunk requested a block ago lands in the ring, the next one is requested, and the block's 16
             // residual words come out of the ring (they lie in chunks p0 >> 4 and (p0 >> 4) + 1)
             XPNG_RB_PUT(G, (p0 >> 4) + 1);
@@ -1364,18 +1376,47 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
                 // RGB: the (marker) top byte of a pixel word is dropped; four pixels are 12 consecutive bytes at any alignment
                 typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
                 const uint32_t q0 = o[0] & 0xFFFFFFu, q1 = o[1] & 0xFFFFFFu, q2 = o[2] & 0xFFFFFFu, q3 = o[3] & 0xFFFFFFu;
-                if (active && x0 >= 0 && x0 + 3 < w) {
-                    *reinterpret_cast<u32x3_a1 *>(drow + 3ll * x0) = u32x3_a1{q0 | (q1 << 24), (q1 >> 8) | (q2 << 16), (q2 >> 16) | (q3 << 8)};
-                } else if (active) {
-                    const uint32_t pk[4] = {q0, q1, q2, q3};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int32_t x = x0 + k;
-                        if (x >= 0 && x < w) { uint8_t *qd = drow + 3ll * x; qd[0] = (uint8_t)pk[k]; qd[1] = (uint8_t)(pk[k] >> 8); qd[2] = (uint8_t)(pk[k] >> 16); }
-                    }
-                }
+                const uint32_t ob = (uint32_t)(pb0 + 12 * q) & 127u;
+                *reinterpret_cast<u32x3_a1 *>(reinterpret_cast<uint8_t *>(rout) + ob) = u32x3_a1{q0 | (q1 << 24), (q1 >> 8) | (q2 << 16), (q2 >> 16) | (q3 << 8)};
+                sp_n = ob > 116u ? ob - 116u : sp_n;
             }
           }
+            if (PXSZ == 3) {
+#define XPNG_RB_FLUSH3()                                                                                                                \
+                {                                                                                                                       \
+                    const u32x4 *fp = reinterpret_cast<const u32x4 *>(rout + 16 * ((uint32_t)flc & 1u));                                \
+                    u32x4 v[4] = {fp[0], fp[1], fp[2], fp[3]};                                                                          \
+                    if (((uint32_t)flc & 1u) == 0) {                                                                                    \
+                        const u32x4 sp = *reinterpret_cast<const u32x4 *>(rout + 32);                                                   \
+                        const uint32_t spw[3] = {sp.x, sp.y, sp.z};                                                                     \
+                        uint32_t vw[3] = {v[0].x, v[0].y, v[0].z};                                                                      \
+                        _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                 \
+                            const int32_t nb = (int32_t)sp_n - 4 * j;                                                                   \
+                            const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : (1u << (8 * nb)) - 1u);                          \
+                            vw[j] = (spw[j] & m) | (vw[j] & ~m);                                                                        \
+                        }                                                                                                               \
+                        v[0].x = vw[0]; v[0].y = vw[1]; v[0].z = vw[2];                                                                 \
+                        sp_n = 0;                                                                                                       \
+                    }                                                                                                                   \
+                    _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                                     \
+                        const int32_t lo = flc * 64 + 16 * g;                                                                           \
+                        if (lo >= blo && lo + 16 <= bhi) *reinterpret_cast<u32x4 *>(dalb + lo) = v[g];                                  \
+                        else if (lo + 16 > blo && lo < bhi) {                                                                           \
+                            const uint32_t vv[4] = {v[g].x, v[g].y, v[g].z, v[g].w};                                                    \
+                            _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                             \
+                                const int32_t dlo = lo + 4 * k;                                                                         \
+                                if (dlo >= blo && dlo + 4 <= bhi) *reinterpret_cast<uint32_t *>(dalb + dlo) = vv[k];                    \
+                                else if (dlo + 4 > blo && dlo < bhi) {                                                                  \
+                                    _Pragma("unroll") for (int b = 0; b < 4; b++)                                                       \
+                                        if (dlo + b >= blo && dlo + b < bhi) dalb[dlo + b] = (uint8_t)(vv[k] >> (8 * b));               \
+                                }                                                                                                       \
+                            }                                                                                                           \
+                        }                                                                                                               \
+                    }                                                                                                                   \
+                    flc++;                                                                                                              \
+                }
+                if (64 * (flc + 1) <= pb0 + 48) XPNG_RB_FLUSH3()  // (a block writes 48 bytes: it completes at most one chunk)
+            }
             if (PXSZ == 4) {
                 // the pixel chunk this block completed (the one holding the block's first position) leaves as four 16-byte stores
 #define XPNG_RB_FLUSH(fc_)                                                                                                              \
@@ -1403,6 +1444,12 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
             }
         }
         if (PXSZ == 4) XPNG_RB_FLUSH(po0 >> 4)  // (po0 was advanced past the last block: its chunk holds the tail of the row, if anything)
+        if (PXSZ == 3) {
+            // the tail of the row: every position up to the last block's end has been written; at most two chunks are still in the ring
+            if (64 * flc < bhi) XPNG_RB_FLUSH3()
+            if (64 * flc < bhi) XPNG_RB_FLUSH3()
+        }
+#undef XPNG_RB_FLUSH3
 #undef XPNG_RB_FLUSH
 #undef XPNG_RB_CLAMP
 #undef XPNG_RB_LOAD
