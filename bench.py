@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = {4: 10.0, 3: 7.75}  # read PXSZ + chooser re-read PXSZ/4 + write PXSZ+1
-PMC_FILES = {4: "r02_pmc_transform_rgba.json", 3: "r02_pmc_transform_rgb.json"}
+PMC_FILES = {4: "r03_pmc_transform_rgba.json", 3: "r03_pmc_transform_rgb.json"}
 
 
 # Environment hygiene.  The release library reads only same-bytes form selectors; every XPNG_* variable

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Digest of tools/prof_pmc_transform.sh passes -> profiles/r02_pmc_transform_<mode>.json (what bench.py's roofline.traffic reads).
+"""Digest of tools/prof_pmc_transform.sh passes -> profiles/rNN_pmc_transform_<mode>.json (what bench.py's roofline.traffic reads).
 usage: pmc_transform_digest.py <gpurun_out dir> <mode: rgba|rgb> <batch>"""
 import csv, glob, json, re, sys, collections
 root, mode, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
