@@ -110,7 +110,8 @@ struct xpnghip_ctx {
     std::vector<TileDesc> tiles;  // the N tiles of ONE image (host copy); the device table has B * N entries
     uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
     TileDesc *d_tiles = nullptr;
-    uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (5 symbol planes): allocated on first use (config-2 entry, mode 2, XPNG_UNFUSED)
+    uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (4 or 5 symbol planes) and d_scratch (level-1 stream scratch): allocated on first use
+    uint8_t *d_arena = nullptr;                         // decode planes of a context that never encoded at level 1 (else they live inside d_scratch)
     uint8_t *d_aplane = nullptr;        // alpha symbol plane of the fused form (XPNG_FUSED): allocated on first use
     const uint8_t *alpha_src = nullptr; // where the last encode left its alpha symbols (debug_fetch 5)
     uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
@@ -174,7 +175,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_aplane, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
+    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_aplane, c->d_scratch, c->d_arena, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_blob_in, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
                     c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -226,9 +227,9 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
     ALLOC(c->d_tiles, VN * sizeof(TileDesc));
     // (d_aplane, the alpha symbol plane of the FUSED form, is allocated on its first use: ensure_aplane - 1 B/px the default form
     //  never touches, 1.07 GB per 64-image context of 4096^2 rasters)
-    ALLOC(c->d_scratch, c->scratch_img * batch + 8192);
-    c->dec.arena = c->d_scratch;   // decode keeps its symbol / residual planes in the encode stream scratch (DecodeWs::arena)
-    c->dec.arena_bytes = c->scratch_img * batch + 8192;
+    // (the level-1 stream scratch, 15.5 B/px, is allocated by the first level-1 encode: ensure_scratch; the decode planes, 8 B/px,
+    //  live inside it when it exists and in an allocation of their own otherwise: ensure_arena.  A context that only ever codes
+    //  level 2 - whose own scratch is 40 B/px - does not pay for the level-1 streams: 60 -> 51.5 B/px with the four-plane RGB form)
     ALLOC(c->d_sums, VN * 16);
     ALLOC(c->d_ctx_n, VN * 9 * 4);
     ALLOC(c->d_k_n, VN * 4);
@@ -324,6 +325,23 @@ static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1)
 }
 
 // the five symbol planes of the unfused form (BASELINE config-2 entry, mode 2, XPNG_UNFUSED): 5 B/px, allocated on first use
+static int ensure_scratch(xpnghip_ctx *c) {
+    if (c->d_scratch) return 0;
+    const uint64_t bytes = c->scratch_img * c->B + 8192;
+    HIPCHK(hipMalloc((void **)&c->d_scratch, bytes));
+    c->ws_bytes += bytes;
+    return 0;
+}
+// where the decode keeps its symbol / residual planes (DecodeWs::arena): chosen at the context's first decode
+static int ensure_arena(xpnghip_ctx *c) {
+    if (c->dec.arena) return 0;
+    if (c->d_scratch) { c->dec.arena = c->d_scratch; c->dec.arena_bytes = c->scratch_img * c->B + 8192; return 0; }
+    const uint64_t bytes = 8 * c->plane_stride + (2u << 20);
+    HIPCHK(hipMalloc((void **)&c->d_arena, bytes));
+    c->ws_bytes += bytes;
+    c->dec.arena = c->d_arena; c->dec.arena_bytes = bytes;
+    return 0;
+}
 static int ensure_aplane(xpnghip_ctx *c) {
     if (c->d_aplane) return 0;
     HIPCHK(hipMalloc((void **)&c->d_aplane, c->plane_stride + 8192));  // + slack: LDS-ring staging reads whole 1 KB units
@@ -332,8 +350,9 @@ static int ensure_aplane(xpnghip_ctx *c) {
 }
 static int ensure_planes(xpnghip_ctx *c) {
     if (c->d_planes) return 0;
-    HIPCHK(hipMalloc((void **)&c->d_planes, 5 * c->plane_stride + 8192));
-    c->ws_bytes += 5 * c->plane_stride + 8192;
+    const uint64_t np = c->pxsz == 4 ? 5 : 4;  // nl, r, g, b (+ alpha symbols)
+    HIPCHK(hipMalloc((void **)&c->d_planes, np * c->plane_stride + 8192));
+    c->ws_bytes += np * c->plane_stride + 8192;
     return 0;
 }
 
@@ -421,7 +440,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     // the alpha chains start ~5 ms later: measured 16.0 against 13.7 ms per 64 images at 3 slots)
     const bool alpha_pass = fused && PXSZ == 4 && !probe_env("XPNG_ALPHA_IN_FUSED");
     static const size_t pad_tr = probe_pad("XPNG_PAD_TR"), pad_st = probe_pad("XPNG_PAD_ST"), pad_ga = probe_pad("XPNG_PAD_GA");
-    if (fused ? ensure_aplane(c) : ensure_planes(c)) return 1;  // (before their address is taken below)
+    if ((fused ? ensure_aplane(c) : ensure_planes(c)) || ensure_scratch(c)) return 1;  // (before their address is taken below)
     XPNG_REQUIRE(fused ? (const void *)c->d_aplane : (const void *)c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
                  c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->h_total);
     const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
@@ -586,7 +605,8 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     HIPCHK(hipMemsetAsync(c->d_status, 0, 4, s));
     uint32_t max_w = 0, max_h = 0;
     for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
-    XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles);
+    if (ensure_arena(c)) return 1;
+    XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles, c->dec.arena);
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
         XPNG_REQUIRE(c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2);
@@ -660,8 +680,10 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
     } else if (what == 5 && c->alpha_src) {
         src = c->alpha_src + t.pbase; bytes = t.n;
     } else if (what >= 1 && what <= 5) {
-        if (!c->d_planes) return -1;  // the five planes exist after xpnghip_m1_transform_device (config-2 entry) or a mode-2 encode
+        if (!c->d_planes || (what == 5 && c->pxsz != 4)) return -1;  // the five planes exist after xpnghip_m1_transform_device (config-2 entry) or a mode-2 encode
         src = c->d_planes + (uint64_t)(what - 1) * c->plane_stride + t.pbase; bytes = t.n;
+    } else if (what >= 10 && what <= 29 && !c->d_scratch) {
+        return -1;  // no level-1 encode has run on this context
     } else if (what >= 10 && what <= 18) {
         if (!d2h(tmp, c->d_ctx_n + tile * 9, 36)) return -1;
         src = c->d_scratch + t.sbase + off_ctx(t.n, what - 10); bytes = tmp[what - 10];
