@@ -533,17 +533,19 @@ __global__ __launch_bounds__(THREADS) void k_dec_alpha(const DecTile *__restrict
 // Output: nl sequence in coded-pixel order.      grid = tiles, block = 64.
 // core of the walk: `base` = 256-byte aligned start of the tile's symbol area, qs = this lane's queue start inside it
 // (lanes 0..8), total = number of symbols to produce.  Single-wave workgroup.
+constexpr uint32_t WALK_RING = 512, WALK_UNIT = WALK_RING / 2;  // LDS ring of one context queue, and the unit it is refilled in
 __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in, uint32_t total, uint8_t *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63;
-    // queue supply: every queue is staged through its own 1 KB LDS ring in 512-byte units (coalesced copies by half a
-    // wave, triggered at 8-step block boundaries when a queue's read position nears the end of what is staged).
-    __shared__ __align__(16) uint8_t qring[9][1024];
+    // queue supply: every queue is staged through its own 512-byte LDS ring in 256-byte units (coalesced copies by a quarter
+    // of the wave, triggered at 8-step block boundaries when a queue's read position nears the end of what is staged).  (1 KB
+    // rings until round 3: the walk waves of a pipelined batch held 9 KB of LDS each for their whole life.)
+    __shared__ __align__(16) uint8_t qring[9][WALK_RING];
     const uint32_t qs = lane < 9 ? qs_in : 0;
     const uint32_t qsa = qs & ~15u;  // 16-byte aligned start of this lane's queue inside the tile's symbol area
     for (uint32_t c = 0; c < 9; c++) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, (int)c);
         const uint4 *src = reinterpret_cast<const uint4 *>(base + a) + lane;
-        reinterpret_cast<uint4 *>(qring[c])[lane] = src[0];  // 64 lanes x 16 B = both 512-byte units
+        if (lane < WALK_RING / 16) reinterpret_cast<uint4 *>(qring[c])[lane] = src[0];  // both units
     }
     __syncthreads();
     uint32_t filled = 2;                      // units staged for this lane's queue
@@ -554,7 +556,7 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
     uint32_t rdpos = (p0 & ~7u) + 8;          // next ring position to load into the register window
     uint32_t cur = 0;
     auto restage = [&]() {  // uniform entry; copies one more unit for every queue that is within 32 bytes of its staged end
-        uint64_t m = __ballot(lane < 9 && rdpos + 32 >= filled * 512u);
+        uint64_t m = __ballot(lane < 9 && rdpos + 32 >= filled * WALK_UNIT);
         if (m == 0) return;
         __syncthreads();
         while (m) {
@@ -562,9 +564,9 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
             m &= m - 1;
             const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, c);
             const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)filled, c);
-            if (lane < 32) {
-                const uint4 v = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * 32];
-                reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * 32 + lane] = v;
+            if (lane < WALK_UNIT / 16) {
+                const uint4 v = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * (WALK_UNIT / 16)];
+                reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * (WALK_UNIT / 16) + lane] = v;
             }
             if ((int)lane == c) filled++;
         }
@@ -576,7 +578,7 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
         win >>= mine ? 8 : 0;
         have -= mine ? 1u : 0u;
         if (have == 0) {  // divergent, once per 8 pops of a queue: next 8 symbols from the LDS ring
-            win = *reinterpret_cast<const uint64_t *>(&qring[ql][rdpos & 1023u]);
+            win = *reinterpret_cast<const uint64_t *>(&qring[ql][rdpos & (WALK_RING - 1)]);
             rdpos += 8;
             have = 8;
         }
@@ -617,16 +619,16 @@ __device__ inline void ctx_walk(const uint8_t *__restrict__ base, uint32_t qs_in
 #define XPNG_WR(k)                                                                                                                  \
     ".Lwr%=_" #k ":\n s_lshr_b32 s72, m0, 1\n s_nop 3\n v_readlane_b32 s74, %[w0], s72\n s_and_b32 s74, s74, 0x0f0f0f0f\n s_mov_b32 s75, 1\n"   \
     "v_cmp_eq_u32 vcc, s72, %[lanev]\n s_and_saveexec_b64 s[76:77], vcc\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %[w0], %[w1]\n"               \
-    "v_and_b32 %[vt], 0x3ff, %[rd]\n v_add_u32 %[vt], %[vt], %[rbase]\n ds_read_b32 %[w1], %[vt]\n v_add_u32 %[rd], 4, %[rd]\n"           \
+    "v_and_b32 %[vt], 0x1ff, %[rd]\n v_add_u32 %[vt], %[vt], %[rbase]\n ds_read_b32 %[w1], %[vt]\n v_add_u32 %[rd], 4, %[rd]\n"           \
     "s_mov_b64 exec, s[76:77]\n s_branch .Lwa%=_" #k "\n"
 __device__ inline void ctx_walk_salu(const uint8_t *__restrict__ base, uint32_t qs_in, uint32_t total, uint8_t *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63;
-    __shared__ __align__(16) uint8_t qring[9][1024];
+    __shared__ __align__(16) uint8_t qring[9][WALK_RING];
     const uint32_t qs = lane < 9 ? qs_in : 0;
     const uint32_t qsa = qs & ~15u;
     for (uint32_t c = 0; c < 9; c++) {
         const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, (int)c);
-        reinterpret_cast<uint4 *>(qring[c])[lane] = (reinterpret_cast<const uint4 *>(base + a) + lane)[0];  // 64 lanes x 16 B = both 512-byte units
+        if (lane < WALK_RING / 16) reinterpret_cast<uint4 *>(qring[c])[lane] = (reinterpret_cast<const uint4 *>(base + a) + lane)[0];  // both units
     }
     __syncthreads();
     uint32_t filled = 2;                      // units staged for this lane's queue
@@ -638,8 +640,8 @@ __device__ inline void ctx_walk_salu(const uint8_t *__restrict__ base, uint32_t 
     const uint32_t rbase = (uint32_t)(uintptr_t)&qring[ql][0];  // LDS byte address of this lane's ring (low 32 bits of the flat address)
     uint32_t cur = 0;
     for (uint32_t k = 0; k < total; k += 64) {
-        {   // stage one more 512-byte unit for every queue whose reads can reach the end of what is staged within this block
-            uint64_t m = __ballot(lane < 9 && rd + 96 >= filled * 512u);
+        {   // stage one more unit for every queue whose reads can reach the end of what is staged within this block
+            uint64_t m = __ballot(lane < 9 && rd + 96 >= filled * WALK_UNIT);
             if (m) {
                 __syncthreads();
                 while (m) {
@@ -647,7 +649,7 @@ __device__ inline void ctx_walk_salu(const uint8_t *__restrict__ base, uint32_t 
                     m &= m - 1;
                     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)qsa, c);
                     const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)filled, c);
-                    if (lane < 32) reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * 32 + lane] = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * 32];
+                    if (lane < WALK_UNIT / 16) reinterpret_cast<uint4 *>(qring[c])[(u & 1u) * (WALK_UNIT / 16) + lane] = (reinterpret_cast<const uint4 *>(base + a) + lane)[u * (WALK_UNIT / 16)];
                     if ((int)lane == c) filled++;
                 }
                 __syncthreads();

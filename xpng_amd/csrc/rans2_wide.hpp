@@ -24,10 +24,10 @@ struct WPrep {
     uint64_t st[2];             // final states
 };
 __device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 + c * 256 : 0; }
-// Compact form of an alpha table (streams that use at most WTC_CAP of the 256 symbols, i.e. nearly all): a symbol -> rank
-// byte map followed by the entries of the used symbols in symbol order.  1 KB instead of 4 KB of LDS per resident stream:
-// the LDS a chain wave holds for its whole life is what limits how many chains of a pipelined batch run at once.
-constexpr uint32_t WTC_CAP = 48, WTC_BYTES = 256 + WTC_CAP * 16;
+// (The alpha tables, 4 KB each, never enter LDS: the chain gathers the entries of a block from the table in global memory
+//  - L2 - one block ahead.  Rounds 1-3 kept a 1 KB compact form per resident stream in LDS; LDS bytes x residency time summed
+//  over the kernels of a pipelined step is what the step time tracks, and 162 waves x 37 KB x 26 ms was the
+//  second largest item of that sum.)
 
 // streams [c_first, c_first + c_count) of every tile (the alpha streams, c = 9, are prepared and chained while the stream-
 // formation kernel is still producing the context streams: they only need the transform's alpha plane)
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                    uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
-                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF, uint8_t *__restrict__ wtabc) {
+                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
@@ -68,20 +68,6 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     EncSym *gt = reinterpret_cast<EncSym *>(wtab + (uint64_t)tile * WTAB_TILE_BYTES + wtab_off(c));
     uint16_t *gF = wF + ((uint64_t)tile * 10 + c) * 256;
     for (uint32_t i = lane; i < N; i += 64) { gt[i] = tab[i]; gF[i] = (uint16_t)hist[i]; }
-    if (c == 9 && distinct <= WTC_CAP) {  // compact table: rank of symbol i = used symbols below it
-        uint8_t *gm = wtabc + (uint64_t)tile * WTC_BYTES;
-        EncSym *ge = reinterpret_cast<EncSym *>(gm + 256);
-        const uint32_t b = lane * 4;
-        uint32_t used[4], cntl = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { used[q] = (b + q < N && hist[b + q] != 0) ? 1u : 0u; cntl += used[q]; }
-        uint32_t r = wave_scan_incl(cntl) - cntl, pk = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (used[q]) { pk |= r << (8 * q); ge[r] = tab[b + q]; r++; }
-        }
-        reinterpret_cast<uint32_t *>(gm)[lane] = pk;  // unused symbols map to rank 0 (never looked up by an active step)
-    }
     if (lane == 0) *p = WPrep{1, N, distinct, 0, {0, 0}};
 }
 
@@ -95,40 +81,39 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
 // So no s_waitcnt for a global access sits in the dependent chain (a conditional store per step does exactly that on
 // gfx9, where stores count on vmcnt).
 typedef uint32_t u32x4_enc __attribute__((ext_vector_type(4)));
-template <bool BIG> constexpr uint32_t chain2_ltab_bytes() { return 32u * ((BIG ? WTC_BYTES : 144u) + 16u); }
+template <bool BIG> constexpr uint32_t chain2_ltab_bytes() { return BIG ? 0u : 32u * (144u + 16u); }
 template <bool BIG> constexpr size_t chain2_lds_bytes() { return chain2_ltab_bytes<BIG>() + 32u * 32u * 4u; }  // dynamic LDS of one launch (common.hpp: why dynamic)
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab,
-                                                     const uint8_t *__restrict__ wtabc) {
+                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
     constexpr uint32_t TPW = 32;                  // tiles (streams) per wave: every lane carries a state (alpha ran 16 per wave while its tables took 4 KB of LDS each)
-    // bytes of one encoder table in LDS: alpha = the compact form (a stream with more than WTC_CAP used symbols reads its
-    // entries from the full table in HBM instead); a context stream has the nine symbols nl = 0..8
-    constexpr uint32_t TAB = BIG ? WTC_BYTES : 144;
+    // bytes of one encoder table in LDS: a context stream has the nine symbols nl = 0..8 (the alpha class keeps none there)
+    constexpr uint32_t TAB = 144;
     constexpr uint32_t TSTRIDE = TAB + 16;        // +4 banks per table: lanes mostly look up the same symbol
     constexpr uint32_t SH = BIG ? 1 : 0;          // byte phase of the symbols inside 16-byte chunks (alpha symbol of pixel i is plane byte i)
     constexpr int PB = BIG ? 15 : 12;
-    static_assert(TPW * TSTRIDE == chain2_ltab_bytes<BIG>() && (TPW * TSTRIDE) % 16 == 0, "LDS layout");
+    static_assert((BIG || TPW * TSTRIDE == chain2_ltab_bytes<BIG>()) && (TPW * TSTRIDE) % 16 == 0, "LDS layout");
     extern __shared__ __align__(16) uint8_t chain2_lds[];
-    uint8_t *const ltab = chain2_lds;                                                      // [TPW * TSTRIDE]
-    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(chain2_lds + TPW * TSTRIDE);       // [TPW * 32] per stream: 16 staged words + 16 nobody reads
+    uint8_t *const ltab = chain2_lds;                                                               // [TPW * TSTRIDE] (context class only)
+    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(chain2_lds + chain2_ltab_bytes<BIG>());     // [TPW * 32] per stream: 16 staged words + 16 nobody reads
     __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t c = BIG ? 9 : blockIdx.x % 9, grp = BIG ? blockIdx.x : blockIdx.x / 9;
     const uint32_t j = grp * TPW + k;
     bool live = k < TPW && j < total;
-    for (uint32_t ts = 0; ts < TPW; ts++) {
-        const uint32_t jj = grp * TPW + ts;
-        if (jj >= total) break;
-        const uint4 *src = BIG ? reinterpret_cast<const uint4 *>(wtabc + (uint64_t)vtile(sel, jj) * WTC_BYTES)
-                               : reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES + wtab_off(c));
-        uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * TSTRIDE);
-        for (uint32_t i = lane; i < TAB / 16; i += 64) dst[i] = src[i];  // (a stream without a compact table copies bytes nobody reads)
+    if (!BIG) {
+        for (uint32_t ts = 0; ts < TPW; ts++) {
+            const uint32_t jj = grp * TPW + ts;
+            if (jj >= total) break;
+            const uint4 *src = reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES + wtab_off(c));
+            uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * TSTRIDE);
+            for (uint32_t i = lane; i < TAB / 16; i += 64) dst[i] = src[i];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t tile = vtile(sel, live ? j : 0);
     const TileDesc *t = tiles + tile;
     uint8_t *sc = scratch + t->sbase;
@@ -169,39 +154,23 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         sy0 = __builtin_amdgcn_perm(d1, d0, selb);
         sy1 = __builtin_amdgcn_perm(d3, d2, selb);
     };
-    // BIG: the 8 table entries of a block are fetched ONE BLOCK AHEAD (its symbols land two blocks ahead), from the compact table
-    // in LDS (symbol -> rank byte -> entry) or, for a stream with more than WTC_CAP used symbols, from its full table in HBM
-    // (global address space: a pointer computed from a kernel argument through a struct would be generic, and flat loads also
-    // count on lgkmcnt); no table access inside a block, and every load has a whole block to return
-    const bool cmp = BIG && live && p->distinct <= WTC_CAP;
-    const uint8_t *lmap = ltab + (k < TPW ? k : 0) * TSTRIDE;
-    const EncSym *lent = reinterpret_cast<const EncSym *>(lmap + 256);
+    // BIG: the 8 table entries of a block are fetched ONE BLOCK AHEAD (its symbols land two blocks ahead) from the stream's
+    // table in global memory (global address space: a pointer computed from a kernel argument through a struct would be
+    // generic, and flat loads also count on lgkmcnt); no table access inside a block, and every load has a whole block to return
     typedef const __attribute__((address_space(1))) u32x4_enc *gent;
     const gent gfull = (gent)(uintptr_t)(wtab + (uint64_t)tile * WTAB_TILE_BYTES);
     constexpr uint32_t cmpl_base = 1u << PB;
     constexpr int thr_shift = 31 - PB;
     uint64_t s = RANS_L;
     uint32_t cnt = 0;
-    // The main loop exists twice for the alpha class: with the entries from LDS (every stream of the wave has a compact table:
-    // wave-uniform) or from HBM.  One loop with both sources would merge two definitions of the in-flight registers, and the
-    // compiler implements the merge as copies right behind the loads - a wait for loads that were issued a moment ago.
-    auto run = [&](auto lds_entries) __attribute__((always_inline)) {
-    constexpr bool LDSE = decltype(lds_entries)::value;
     EncSym E[8], En[8];
     auto entries = [&]() __attribute__((always_inline)) {  // entries of the block whose symbols are in sy0/sy1 -> En
         uint32_t sy[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) sy[u] = ((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u;
-        if constexpr (LDSE) {
-            uint32_t r[8];
+        // (lanes without a stream read their placeholder tile's table: no branch around the loads)
 #pragma unroll
-            for (int u = 0; u < 8; u++) r[u] = lmap[sy[u]];
-#pragma unroll
-            for (int u = 0; u < 8; u++) En[u] = lent[r[u]];
-        } else {  // (lanes without a stream read their placeholder tile's table: no branch around the loads)
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; En[u] = EncSym{v.x, v.y, v.z, v.w}; }
-        }
+        for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; En[u] = EncSym{v.x, v.y, v.z, v.w}; }
     };
     request(0); land(); request(1);
     EncSym e = EncSym{0, 0, 0, 0};
@@ -264,10 +233,6 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         if (BIG) entries();
         else e = tab[sy0 & 255u];
     }
-    };
-    if (!BIG) run(std::false_type{});
-    else if (__ballot(live && !cmp) == 0) run(std::true_type{});
-    else run(std::false_type{});
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
     XPNG_PROBE_END(BIG ? 2 : 1)
 }

@@ -133,7 +133,7 @@ struct xpnghip_ctx {
     std::vector<const void *> h_dec_in_ptrs;
     std::vector<void *> h_dec_out_ptrs;
     WPrep *d_wprep = nullptr;   // wide entropy stage: per (tile, stream) record, encoder tables, normalised frequencies
-    uint8_t *d_wtab = nullptr, *d_wtabc = nullptr;
+    uint8_t *d_wtab = nullptr;
     uint32_t n_big = 0;
     uint16_t *d_wF = nullptr;
     // mode 2 (RGB slow level): allocated on first use
@@ -177,7 +177,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_tiles, c->d_planes, c->d_aplane, c->d_scratch, c->d_arena, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_blob_in, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
-                    c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
+                    c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
     if (c->ev_enc_fork) (void)hipEventDestroy(c->ev_enc_fork);
@@ -243,7 +243,6 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
 #endif
     ALLOC(c->d_wprep, VN * 10 * sizeof(WPrep));
     ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096);
-    ALLOC(c->d_wtabc, VN * WTC_BYTES + 4096);
     ALLOC(c->d_wF, VN * 10 * 512);
     ALLOC(c->d_blob_len, (uint64_t)batch * 8);
     ALLOC(c->d_status, 64);
@@ -442,7 +441,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     static const size_t pad_tr = probe_pad("XPNG_PAD_TR"), pad_st = probe_pad("XPNG_PAD_ST"), pad_ga = probe_pad("XPNG_PAD_GA");
     if ((fused ? ensure_aplane(c) : ensure_planes(c)) || ensure_scratch(c)) return 1;  // (before their address is taken below)
     XPNG_REQUIRE(fused ? (const void *)c->d_aplane : (const void *)c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
-                 c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wtabc, c->d_wF, c->h_total);
+                 c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wF, c->h_total);
     const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
     const bool alpha_side = !narrow && PXSZ == 4;
     if (alpha_side && !c->enc_side) {
@@ -451,8 +450,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
     }
     auto alpha_branch = [&](hipStream_t as) -> int {  // alpha plane -> tables -> chains, on the side stream
-        if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
+        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
         return 0;
     };
@@ -488,8 +487,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, c->d_wtabc);
-        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, c->d_wtabc);
+        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
+        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
         if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
         if (!dbg_skip("finish")) k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
