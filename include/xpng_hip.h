@@ -16,7 +16,7 @@
  * lock is held while a call runs.  A device-resident context (xpnghip_ctx) is a single-queue object owned by its caller.
  *
  * Environment read by the release library (each selects between forms that produce the same bytes):
- * XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS, XPNG_FUSED, XPNG_UNFUSED, XPNG_SPLIT, XPNG_NO_SPLIT.  Switches that
+ * XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS, XPNG_SPLIT, XPNG_NO_SPLIT.  Switches that
  * exist for timing studies (kernel knock-outs, LDS pads, stamps, the wave probe, fake devices) are compiled only into
  * libxpng_hip_probes.so (`make probes`).
  */

@@ -106,7 +106,7 @@ def test_stage_planes_and_streams_match_oracle(gpu, po, kind, w, h, alpha):
         for k in ("nl", "r", "g", "b") + (("a",) if ch == 4 else ()):
             assert np.array_equal(ctx.fetch(k, ti), planes[k]), (ti, k)
         all_planes.append((pr, planes))
-    # full encode (default form: through the planes; the fused form is covered by test_fused_transform_routing_path), then the rANS blocks
+    # full encode, then the rANS blocks
     ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
     for ti, t in enumerate(ctx.tiles()):
         pr, planes = all_planes[ti]
@@ -743,7 +743,7 @@ def test_concurrent_calls_really_overlap(gpu):
 def test_first_call_on_a_fresh_context_may_be_anything(gpu, po):
     """Regression for the abort of gpurun_out/r2_t14.log: a context's lazily allocated buffers (the five
     symbol planes, the mode-2 workspace) are allocated by whichever launch sequence needs them first - a mode-2 encode, the
-    transform-only entry, a fused or unfused mode-1 encode - and a launch never hands a null workspace pointer to a kernel
+    transform-only entry, a mode-1 encode - and a launch never hands a null workspace pointer to a kernel
     (that is a GPU fault, i.e. abort(), not an error return)."""
     import torch
     import xpng_amd
@@ -781,47 +781,46 @@ def test_first_call_on_a_fresh_context_may_be_anything(gpu, po):
 
 
 @pytest.mark.parametrize("force_wide", [False, True])
-def test_fused_transform_routing_path(gpu, manifest, po, tmp_path, monkeypatch, force_wide):
-    """XPNG_FUSED=1: transform and routing in one kernel (k_m1_fused, no nl / r / g / b planes in HBM; alpha symbols from
-    k_alpha_syms).  Same bytes as the default form: every small golden at level 1, the stage outputs of an RGBA and an RGB raster
-    (context streams, k words, alpha plane), and a batch."""
+def test_context_stream_places_follow_their_lengths(gpu, po, monkeypatch, force_wide):
+    """Stream-scratch layout (common.hpp): the nine context streams of a tile lie back to back, each in the room its length needs;
+    the lengths come from k_m1_count (a histogram of the nl plane) BEFORE the routing kernel writes a byte.  Rasters that push
+    the layout: nearly every pixel in one context (flat), all nine contexts busy (photo, noise), transparent runs (RGBA: coded
+    pixels skip them), tiles of one row / one column, and a batch.  Every stream, k and every block byte-equal to the oracle."""
     import torch
+    import xpng_amd
     from xpng_amd.synth import synth_raster
-    monkeypatch.setenv("XPNG_FUSED", "1")
     if force_wide:
         monkeypatch.setenv("XPNG_WIDE_RANS", "1")
-    checked = 0
-    for name, ent in small_entries(manifest):
-        g = ent.get("L1")
-        if g is None:
-            continue
-        raster = golden_raster(name, ent)
-        out = tmp_path / "o.xpng"
-        gpu.store(1, raster, str(out))
-        data = out.read_bytes()
-        assert len(data) == g["size"] and md5(data) == g["md5"], name
-        checked += 1
-    assert checked >= 120
-    for (w, h, alpha) in [(1333, 901, True), (1501, 1203, False)]:
-        raster = synth_raster("photo", w, h, alpha)
-        ch = raster.shape[2]
-        ctx = gpu.Context(w, h, ch)
+    cases = [("photo", 700, 500, True), ("photo", 700, 500, False), ("noise", 300, 200, True), ("flat", 500, 460, False),
+             ("photo", 1200, 3, False), ("photo", 5, 900, True)]
+    for kind, w, h, alpha in cases:
+        raster = synth_raster(kind, w, h, alpha, seed=11)
+        if alpha:
+            raster[h // 3: h // 3 + 7, :, 3] = 0          # runs of invisible pixels, also at the end of a row
+            raster[-1, -max(1, w // 4):, 3] = 0           # the tile's LAST pixels are not coded: "last coded pixel" is further up
+        hh, ww, ch = raster.shape
+        ctx = xpng_amd.Context(ww, hh, ch)
         d_r = torch.from_numpy(raster).cuda()
-        d_b = torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        d_b = torch.zeros(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda")
         n = ctx.encode_device(1, d_r.data_ptr(), d_b.data_ptr())
-        assert d_b[:n].cpu().numpy().tobytes() == po.encode_tiles(1, raster)
+        assert d_b[:n].cpu().numpy().tobytes() == po.encode_tiles(1, raster), (kind, w, h, alpha)
         for ti, t in enumerate(ctx.tiles()):
             pr, _ = po.choose_predictor(raster, t)
             planes = po.m1_planes(raster, t, pr)
             st = po.m1_streams(raster, t, planes)
             for c in range(9):
-                assert np.array_equal(ctx.fetch(10 + c, ti), st["ctx"][c]), (ti, c)
-            assert np.array_equal(ctx.fetch("k", ti).view(np.uint32), st["k"])
-            if ch == 4:
-                assert np.array_equal(ctx.fetch("a", ti)[1:], planes["a"][1:]), ti
+                assert np.array_equal(ctx.fetch(10 + c, ti), st["ctx"][c]), (kind, w, h, alpha, ti, c)
+            assert np.array_equal(ctx.fetch("k", ti).view(np.uint32), st["k"]), (kind, w, h, alpha, ti)
         ctx.close()
-
-
+    # a batch of distinct rasters through one launch sequence
+    rs = [synth_raster("photo", 900, 700, True, seed=20 + i) for i in range(5)]
+    ctx = xpng_amd.Context(900, 700, 4, batch=5)
+    d_rs = [torch.from_numpy(r).cuda() for r in rs]
+    d_bs = [torch.zeros(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in rs]
+    sizes = ctx.encode_device_batch(1, [d.data_ptr() for d in d_rs], [d.data_ptr() for d in d_bs])
+    for r, d, n in zip(rs, d_bs, sizes):
+        assert d[:n].cpu().numpy().tobytes() == po.encode_tiles(1, r)
+    ctx.close()
 @pytest.mark.gpu
 @pytest.mark.parametrize("pb", [13, 15])
 def test_context_stream_with_more_probability_bits_on_the_wide_path(gpu, po, monkeypatch, pb):

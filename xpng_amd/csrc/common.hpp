@@ -10,9 +10,9 @@
 namespace xpng {
 
 // ---- build flavours ---------------------------------------------------------------------------------------------------
-// The release library (libxpng_hip.so) reads exactly these environment variables, each of which selects between forms that
-// produce the SAME bytes (INTEGRATION.md lists them): XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS, XPNG_FUSED,
-// XPNG_UNFUSED, XPNG_SPLIT, XPNG_NO_SPLIT (and the runtime's own GPU_MAX_HW_QUEUES).  Everything that exists for timing
+// The release library (libxpng_hip.so) reads exactly these six environment variables, each of which selects between forms that
+// produce the SAME bytes (INTEGRATION.md lists them): XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS,
+// XPNG_SPLIT, XPNG_NO_SPLIT (and the runtime's own GPU_MAX_HW_QUEUES).  Everything that exists for timing
 // studies - kernel knock-outs, unused-LDS pads, no-store switches, phase stamps, the wave probe, stream priorities, fake
 // devices - is compiled only into libxpng_hip_probes.so (-DXPNG_PROBES, `make probes`; tools/ load that one): a product
 // library whose output can be falsified through the environment is not shippable.
@@ -116,31 +116,39 @@ __host__ __device__ inline uint32_t vtile(const TileSel &s, uint32_t j) {
 }
 __host__ __device__ inline uint32_t imglin(const TileSel &s, uint32_t vt) { const uint32_t img = vt / s.N; return img * s.cnt + (vt - img * s.N - s.t0); }
 
-// Stream-scratch layout of one tile, all offsets relative to TileDesc::sbase and derived from n only,
-// so that host and device agree without a table.  Capacities are worst cases:
-//   context stream  : <= n-1 symbols, 1 B each
-//   k bit stream    : 8*pxsz bits + <= 24 bits/pixel
+// Stream-scratch layout of one tile, all offsets relative to TileDesc::sbase:
+//   [k bit stream: 8*pxsz bits + <= 24 bits/pixel][alpha block][nine context streams, back to back][nine context blocks, back to back]
+// The k region and the alpha block are sized for the worst case (their places must not depend on anything computed on the
+// device: the alpha chains start while the routing kernel is still running).  The nine context streams share the tile's
+// n - 1 coded pixels, and how they share them is known BEFORE the routing kernel writes a byte: stream c receives the nl of
+// every coded pixel whose predecessor's nl is c, so its length is hist[c] - [c == nl of the last coded pixel] + [c == 0], a
+// histogram of the nl plane (k_m1_count).  So each stream gets the room its length needs (+ slack for the 16-byte block loads
+// of the chains) and the region is n + 9 * 96 bytes, not nine times n: 7.5 instead of 15.5 bytes of scratch per pixel.
 //   rANS v2 block   : 12 B header + ceil(m*pb/32) words + 16 B states + table (<= 256*16 bits), m = symbols of the stream
 __host__ __device__ inline uint64_t rup(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
-__host__ __device__ inline uint64_t ctx_cap(uint32_t n) { return rup((uint64_t)n + 64, 256); }
 __host__ __device__ inline uint64_t kw_cap(uint32_t n) { return rup(3ull * n + 64, 256); }
 __host__ __device__ inline uint64_t ctxblk_cap(uint32_t n) { return rup(3ull * n / 2 + 128, 256); }
 __host__ __device__ inline uint64_t alphablk_cap(uint32_t n) { return rup(2ull * n + 1280, 256); }
-__host__ __device__ inline uint64_t off_ctx(uint32_t n, int c) { return (uint64_t)c * ctx_cap(n); }
-__host__ __device__ inline uint64_t off_kw(uint32_t n) { return 9 * ctx_cap(n); }
-// Block slots: the alpha block first (its place must not depend on the context stream lengths: the alpha chains start while
-// the stream kernel is still running), then the nine context blocks back to back, each sized by ITS stream's length cn[c]
-// (known once k_m1_streams has run) instead of nine slots of the worst case n: the streams share n - 1 symbols, so the nine
-// take <= 1.5 n + 9 * 383 bytes together, not 13.5 n.
+__host__ __device__ inline uint64_t ctx_slot(uint32_t m) { return rup((uint64_t)m + 32, 64); }       // room of a context stream of m symbols
+__host__ __device__ inline uint64_t ctx_region(uint32_t n) { return rup((uint64_t)n + 9 * 96, 256); }  // >= sum of the nine slots
+__host__ __device__ inline uint64_t off_kw(uint32_t) { return 0; }
+// cn: the tile's nine context stream lengths (ctx_n + tile * 9)
+__host__ __device__ inline uint64_t off_ctx(uint32_t n, const uint32_t *cn, int c) {
+    uint64_t o = kw_cap(n) + alphablk_cap(n);
+    for (int i = 0; i < c; i++) o += ctx_slot(cn[i]);
+    return o;
+}
+// Block slots: the alpha block right behind k, the nine context blocks behind the stream region, each sized by ITS stream's
+// length: the streams share n - 1 symbols, so the nine take <= 1.5 n + 9 * 383 bytes together, not 13.5 n.
 __host__ __device__ inline uint64_t off_blk(uint32_t n, const uint32_t *cn, int c) {  // c = 0..8 context blocks, 9 = alpha
-    uint64_t o = off_kw(n) + kw_cap(n);
+    uint64_t o = kw_cap(n);
     if (c == 9) return o;
-    o += alphablk_cap(n);
+    o += alphablk_cap(n) + ctx_region(n);
     for (int i = 0; i < c; i++) o += ctxblk_cap(cn[i]);
     return o;
 }
 __host__ __device__ inline uint64_t tile_scratch_bytes(uint32_t n) {
-    return off_kw(n) + kw_cap(n) + alphablk_cap(n) + rup(3ull * n / 2 + 9 * 383, 256);
+    return kw_cap(n) + alphablk_cap(n) + ctx_region(n) + rup(3ull * n / 2 + 9 * 383, 256);
 }
 
 // ---- integer helpers shared by encode and decode (reference libxpng.c:19-30) ----------------------

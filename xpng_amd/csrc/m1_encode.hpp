@@ -540,20 +540,80 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
 }
 
 // --------------------------------------------------------------------------------------------------
+// Lengths of the nine context streams of a tile, BEFORE anything is routed (common.hpp: stream-scratch layout).  Stream c gets
+// the nl of every coded pixel whose predecessor (the previous coded pixel; the first one's is 0, libxpng.c:497-508) has nl = c:
+//     len[c] = hist[c] - [c == nl of the last coded pixel] + [c == 0]            (all zero when the tile codes no pixel)
+// with hist = histogram of the nl plane over coded pixels.  One 256-thread workgroup per tile reads the plane once (16 pixels
+// per thread and step; nine 7-bit fields of a 64-bit accumulator, spilled into nine counters every 7 steps).
+__global__ __launch_bounds__(256) void k_m1_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint8_t *__restrict__ planes,
+                                                  uint32_t *__restrict__ ctx_n) {
+    const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
+    const TileDesc t = tiles[tile];
+    const uint4 *pnl = reinterpret_cast<const uint4 *>(planes + t.pbase);  // (plane bases are multiples of 256; >= 192 bytes of slack behind a tile)
+    __shared__ uint32_t s_hist[9];
+    __shared__ uint32_t s_last;  // (index of the last coded pixel + 1) << 4 | its nl
+    if (tid < 9) s_hist[tid] = 0;
+    if (tid == 0) s_last = 0;
+    __syncthreads();
+    uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    uint64_t acc = 0;
+    uint32_t pend = 0;
+    auto spill = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) cnt[c] += (uint32_t)(acc >> (7 * c)) & 127u;
+        acc = 0; pend = 0;
+    };
+    for (uint32_t i0 = 16 * tid; i0 < t.n; i0 += 16 * 256) {
+        const uint4 v = pnl[i0 >> 4];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t nl = (w[q >> 2] >> (8 * (q & 3))) & 255u, i = i0 + (uint32_t)q;
+            const bool coded = nl != NL_NONE && i < t.n;
+            const uint32_t f = nl < 8u ? nl : 8u;  // (nl <= 8 for coded pixels)
+            acc += coded ? 1ull << (7 * f) : 0ull;
+            last = coded ? ((i + 1) << 4) | f : last;  // (pixels in increasing order: the last assignment wins)
+        }
+        if (++pend == 7) spill();  // 7 x 16 = 112 <= 127 per field
+    }
+    spill();
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        uint32_t v = cnt[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0 && v) atomicAdd(&s_hist[c], v);
+    }
+    {
+        uint32_t v = last;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
+        if ((tid & 63) == 0 && v) atomicMax(&s_last, v);
+    }
+    __syncthreads();
+    if (tid < 9) {
+        const uint32_t l = s_last;
+        uint32_t len = s_hist[tid];
+        if (l) len = len - ((l & 15u) == tid ? 1u : 0u) + (tid == 0 ? 1u : 0u);
+        ctx_n[(uint64_t)tile * 9 + tid] = len;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // K3  stream formation.  One 1024-thread workgroup walks one tile in raster order, 1024 pixels per step.
 // Three serial couplings of the reference loop become wave-level prefix operations:
 //   (i)  pl = nl of the previous CODED pixel            -> ballot + "highest set bit below me" + carry
 //   (ii) append position inside context stream cx[pl]   -> one ballot/popcount per context (9)
 //   (iii) bit cursor of k (3*nl bits per coded pixel)   -> wave inclusive scan + cross-wave offsets,
 //        bits are OR-ed MSB-first into an LDS word window and spliced into k with a carried partial word.
-// Outputs: ctx streams + their lengths, k words + count.   grid = tiles, block = 1024.
+// Outputs: ctx streams (their lengths and places are known beforehand: k_m1_count), k words + count.   grid = tiles, block = 1024.
 // THREADS = 1024 for a few tiles (shortest serial walk per tile); 256 for large batches: the chain kernels of other
 // batches in flight leave few CUs with room for a 16-wave workgroup, but almost all have room for a 4-wave one.
 template <int PXSZ, int ST_THREADS>
 __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                            const TileDesc *__restrict__ tiles, TileSel sel,
                                                            const uint8_t *__restrict__ planes, uint64_t plane_stride,
-                                                           uint8_t *__restrict__ scratch, uint32_t *__restrict__ ctx_n,
+                                                           uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                            uint32_t *__restrict__ k_n) {
     // One workgroup walks a tile in raster order, ST_THREADS * 4 pixels per iteration: a lane owns 4 consecutive pixels
     // (one dword of each plane).  Per iteration: the previous-coded-nl chain (pl), a packed prefix sum of the nine
@@ -567,11 +627,10 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     const uint32_t *pg = reinterpret_cast<const uint32_t *>(planes + 2 * plane_stride + t.pbase), *pb = reinterpret_cast<const uint32_t *>(planes + 3 * plane_stride + t.pbase);
     uint8_t *sc = scratch + t.sbase;
     uint32_t *kw = reinterpret_cast<uint32_t *>(sc + off_kw(t.n));
-    const uint32_t cap = (uint32_t)ctx_cap(t.n);
 
     constexpr int ST_WAVES = ST_THREADS / 64, ST_PX = ST_THREADS * 4, ST_WORDS = ST_PX * 24 / 32 + 4, ST_ROUNDS = (ST_WORDS + ST_THREADS - 1) / ST_THREADS;
     __shared__ uint32_t s_bits[ST_WORDS];
-    __shared__ uint32_t s_run_cnt[9];
+    __shared__ uint32_t s_run_cnt[9];  // next free byte of every context stream, relative to the tile's scratch (starts at the stream's place)
     __shared__ uint32_t s_wave_cnt[ST_WAVES][9];
     __shared__ volatile uint32_t s_base[ST_WAVES][16];
     __shared__ uint32_t s_wave_bits[ST_WAVES];
@@ -581,7 +640,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     const uint8_t *p0 = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
     uint32_t run_bits, wbase, run_pl = 0;  // uniform across the workgroup
     for (int j = tid; j < ST_WORDS; j += ST_THREADS) s_bits[j] = 0;
-    if (tid < 9) s_run_cnt[tid] = 0;
+    if (tid < 9) s_run_cnt[tid] = (uint32_t)off_ctx(t.n, ctx_n + (uint64_t)tile * 9, (int)tid);
     __syncthreads();
     if (PXSZ == 4) {
         if (tid == 0) kw[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8) | p0[3];
@@ -678,7 +737,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
             if (coded[j]) {
                 const uint32_t e = inc[j][0] ? e0 : (inc[j][1] ? e1 : e2);
                 const uint32_t rank = (e >> sh[j]) & 1023u;
-                sc[pl[j] * cap + s_base[wv][pl[j]] + rank] = (uint8_t)nl[j];
+                sc[s_base[wv][pl[j]] + rank] = (uint8_t)nl[j];
             }
             e0 += inc[j][0]; e1 += inc[j][1]; e2 += inc[j][2];
             const uint32_t n1 = nl[j] & 15u;  // (NL_NONE has len 0: v is masked out below)
@@ -719,258 +778,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
         if (run_bits & 31) { kw[wbase] = s_bits[0]; words++; }  // BITSTREAM_END: tail is already left-aligned
         k_n[tile] = words;
     }
-    if (tid < 9) ctx_n[(uint64_t)tile * 9 + tid] = s_run_cnt[tid];
-}
-
-// --------------------------------------------------------------------------------------------------
-// Alpha symbols alone (RGBA): zz(alpha - alpha of the left neighbour; column 0: of the pixel above), libxpng.c:510-511 - they do
-// not depend on the tile's predictor flags, so this small pass (reads the raster, writes 1 B/px) runs before / beside the chooser
-// and lets the alpha rANS chains, the longest serial stage of an encode, start at once while k_m1_fused is still routing.
-// One thread = 4 consecutive pixels of the tile in raster order; grid = tiles * blocks_per_tile, block = 256.
-__global__ __launch_bounds__(256) void k_alpha_syms(const uint8_t *const *__restrict__ rasters, uint64_t bpr, const TileDesc *__restrict__ tiles,
-                                                    TileSel sel, uint32_t blocks_per_tile, uint8_t *__restrict__ aplane) {
-    const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
-    const TileDesc t = tiles[tile];
-    const uint8_t *__restrict__ raster = rasters[t.img];
-    for (uint32_t rep = 0; rep < TG_REPS; rep++) {
-        const uint32_t i0 = ((chunk * TG_REPS + rep) * 256 + threadIdx.x) * 4;
-        if (i0 >= t.n) return;
-        const uint32_t y = i0 / t.w, x = i0 - y * t.w;
-        uint32_t oa = 0;
-        const uint8_t *p = raster + (uint64_t)(t.y + y) * bpr + (uint64_t)(t.x + x) * 4;
-        if (x + 3 < t.w && i0 + 3 < t.n) {  // the four pixels share a row: one 16-byte load + the neighbour that predicts the first
-            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-            const u32x4_a4 c = *reinterpret_cast<const u32x4_a4 *>(p);
-            const uint32_t nb = x ? *reinterpret_cast<const uint32_t *>(p - 4) : (y ? *reinterpret_cast<const uint32_t *>(p - bpr) : 0u);
-            const int a0 = c.x >> 24, a1 = c.y >> 24, a2 = c.z >> 24, a3 = c.w >> 24, an = nb >> 24;
-            oa = (uint32_t)zz_enc(a0 - an) | ((uint32_t)zz_enc(a1 - a0) << 8) | ((uint32_t)zz_enc(a2 - a1) << 16) | ((uint32_t)zz_enc(a3 - a2) << 24);
-        } else {
-            uint32_t xx = x, yy = y;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (i0 + k < t.n) {
-                    const uint8_t *q = raster + (uint64_t)(t.y + yy) * bpr + (uint64_t)(t.x + xx) * 4;
-                    const int ca = q[3], pa = xx ? q[-1] : (yy ? q[3 - (int64_t)bpr] : 0);
-                    oa |= (uint32_t)zz_enc(ca - pa) << (8 * k);
-                }
-                if (++xx == t.w) { xx = 0; yy++; }
-            }
-        }
-        *reinterpret_cast<uint32_t *>(aplane + t.pbase + i0) = oa;
-    }
-}
-
-// --------------------------------------------------------------------------------------------------
-// K2 + K3 fused: the product path's transform -> routing without the symbol planes in between.  One workgroup walks one tile
-// strip by strip (TR_ROWS rows staged in LDS exactly as the transform kernels stage them); a thread computes the symbols of its
-// four consecutive pixels in registers (rgba_group / rgb_group: the transform's arithmetic) and feeds them straight into the
-// routing of k_m1_streams (pl chain, per-context append positions, bit cursor of k: the same wave scans, the same carried
-// state from strip to strip).  Out: the nine context streams + k, and for RGBA the alpha symbol plane (1 B/px: the alpha rANS
-// block reads it).  The nl / r / g / b planes (4 B/px written, 4 B/px read back, 4 B/px of workspace) no longer exist on this
-// path; k_m1_transform_* + k_m1_streams stay as the BASELINE config-2 measurement entry and for mode 2.
-template <int PXSZ, int ST_THREADS>
-__global__ __launch_bounds__(ST_THREADS) void k_m1_fused(const uint8_t *const *__restrict__ rasters, uint64_t bpr, uint64_t raster_bytes,
-                                                         const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ sums,
-                                                         uint8_t *__restrict__ aplane, uint8_t *__restrict__ scratch,
-                                                         uint32_t *__restrict__ ctx_n, uint32_t *__restrict__ k_n) {
-    const uint32_t tile = vtile(sel, blockIdx.x);
-    const TileDesc t = tiles[tile];
-    const uint8_t *__restrict__ raster = rasters[t.img];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint8_t *sc = scratch + t.sbase;
-    uint32_t *kw = reinterpret_cast<uint32_t *>(sc + off_kw(t.n));
-    const uint32_t cap = (uint32_t)ctx_cap(t.n);
-    const int pr = pr_from_sums(sums + (uint64_t)tile * 4, PXSZ, t.w, t.h) & 3;
-
-    constexpr int ST_WAVES = ST_THREADS / 64, ST_PX = ST_THREADS * 4, ST_WORDS = ST_PX * 24 / 32 + 4, ST_ROUNDS = (ST_WORDS + ST_THREADS - 1) / ST_THREADS;
-    constexpr uint32_t PAD = PXSZ == 3 ? TR3_LDS_PAD : 0;
-    __shared__ __align__(16) uint8_t rows[PAD + (TR_ROWS + 1) * TR_PITCH + 16];
-    __shared__ uint32_t s_bits[ST_WORDS];
-    __shared__ uint32_t s_run_cnt[9];
-    __shared__ uint32_t s_wave_cnt[ST_WAVES][9];
-    __shared__ volatile uint32_t s_base[ST_WAVES][16];
-    __shared__ uint32_t s_wave_bits[ST_WAVES];
-    __shared__ uint32_t s_wave_last[ST_WAVES];
-
-    // first pixel: 8*PXSZ raw bits at the head of k (libxpng.c:547)
-    const uint8_t *p0 = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
-    uint32_t run_bits, wbase, run_pl = 0;  // uniform across the workgroup
-    for (int j = tid; j < ST_WORDS; j += ST_THREADS) s_bits[j] = 0;
-    if (tid < 9) s_run_cnt[tid] = 0;
-    __syncthreads();
-    if (PXSZ == 4) {
-        if (tid == 0) kw[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8) | p0[3];
-        run_bits = 32; wbase = 1;
-    } else {
-        if (tid == 0) s_bits[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8);
-        run_bits = 24; wbase = 0;
-    }
-    const uint64_t lt = lanemask_lt();
-    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);
-
-    for (uint32_t y0 = 0; y0 < t.h; y0 += TR_ROWS) {
-        const uint32_t nrows = min(TR_ROWS, t.h - y0);
-        const uint32_t first = y0 ? y0 - 1 : 0, lrows = y0 + nrows - first;  // rows staged: [first, first + lrows)
-        const uint64_t g0 = (uint64_t)(t.y + first) * bpr + (uint64_t)t.x * PXSZ;  // first staged byte
-        __syncthreads();  // the previous strip's readers are done with `rows`
-        {   // ---- phase 1 (as k_m1_transform_*): global -> LDS, 16 bytes per lane per load, every load in flight before the first LDS store
-            const uint32_t row_bytes = t.w * PXSZ;
-            const uint32_t chunks = ((15u + row_bytes + 15u) >> 4) + 1;  // per row, upper bound for any phase
-            constexpr int LD = ((TR_ROWS + 1) * (TR_MAXW * PXSZ / 16 + 3) + ST_THREADS - 1) / ST_THREADS;
-            const uint32_t total_chunks = lrows * chunks;
-            const float inv_chunks = 1.0f / (float)chunks;
-            uint4 v[LD];
-            uint32_t dst[LD];
-#pragma unroll
-            for (int k = 0; k < LD; k++) {
-                const uint32_t idx = tid + (uint32_t)ST_THREADS * k;
-                dst[k] = ~0u;
-                if (idx < total_chunks) {
-                    uint32_t r = (uint32_t)((float)idx * inv_chunks);
-                    if (r * chunks > idx) r--;
-                    if ((r + 1) * chunks <= idx) r++;
-                    const uint32_t ch = idx - r * chunks;
-                    const uint64_t gr = g0 + (uint64_t)r * bpr;
-                    const uint64_t a = (gr & ~15ull) + (uint64_t)ch * 16;
-                    if (a < gr + row_bytes) {
-                        dst[k] = PAD + r * TR_PITCH + ch * 16;
-                        if (a + 16 <= raster_bytes) v[k] = *reinterpret_cast<const uint4 *>(raster + a);
-                        else {  // last chunk of the raster: stay inside the allocation
-                            uint32_t w4[4] = {0, 0, 0, 0};
-                            for (uint32_t q = 0; q < 16; q++) if (a + q < raster_bytes) w4[q >> 2] |= (uint32_t)raster[a + q] << (8 * (q & 3));
-                            v[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
-        }
-        __syncthreads();
-        const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
-        for (uint32_t gb = 0; gb < groups; gb += ST_THREADS) {
-            // ---- the transform of this thread's four pixels, in registers
-            const uint32_t g = gb + tid;
-            uint32_t nl4 = 0xFFFFFFFFu, r4 = 0, g4 = 0, b4 = 0, a4 = 0;
-            if (g < groups) {
-                const uint32_t yy = (4 * g) / t.w, x0 = 4 * g - yy * t.w;
-                if constexpr (PXSZ == 4) {
-                    { const uint32_t pr_ = (pr) & 3u; rgba_group((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4, a4); }  // (predictor flags are wave-uniform runtime values: one copy of the code, not four - the I-cache is shared by every kernel in flight)
-                    if (aplane) *reinterpret_cast<uint32_t *>(aplane + t.pbase + (uint64_t)y0 * t.w + 4 * g) = a4;  // alpha symbols (nullptr: k_alpha_syms has written them)
-                } else {
-                    { const uint32_t pr_ = (pr) & 3u; rgb_group((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, g0, y0, first, strip_px, g, yy, x0, nl4, r4, g4, b4); }  // (predictor flags are wave-uniform runtime values: one copy of the code, not four - the I-cache is shared by every kernel in flight)
-                }
-            }
-            // ---- the routing of k_m1_streams on (nl4, r4, g4, b4)
-            uint32_t nl[4], len[4];
-            bool coded[4];
-            uint32_t lastnl = NL_NONE, lane_len = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                nl[j] = (nl4 >> (8 * j)) & 255u;
-                coded[j] = nl[j] != NL_NONE;
-                lastnl = coded[j] ? nl[j] : lastnl;
-                len[j] = coded[j] ? 3 * nl[j] : 0;
-                lane_len += len[j];
-            }
-            const uint64_t mask = __ballot(nl4 != 0xFFFFFFFFu);
-            const uint64_t lower = mask & lt;
-            const int src_last = mask ? 63 - __clzll((long long)mask) : 0;
-            const uint32_t wave_last = __shfl(lastnl, src_last);
-            if (lane == 0) s_wave_last[wv] = mask ? wave_last : NL_NONE;
-            const int src_prev = lower ? 63 - __clzll((long long)lower) : 0;
-            const uint32_t prev_in_wave = __shfl(lastnl, src_prev);
-            const uint32_t incl = wave_scan_incl(lane_len);
-            if (lane == 63) s_wave_bits[wv] = incl;
-            __syncthreads();  // (A) wave_last / wave_bits visible
-
-            uint32_t carry = run_pl, bit_base = 0, bits_total = 0, new_run_pl = run_pl;
-            for (int w2 = 0; w2 < ST_WAVES; w2++) {
-                const uint32_t wl = s_wave_last[w2], wb = s_wave_bits[w2];
-                if (w2 < (int)wv) { if (wl != NL_NONE) carry = wl; bit_base += wb; }
-                if (wl != NL_NONE) new_run_pl = wl;
-                bits_total += wb;
-            }
-            uint32_t pl[4], sh[4], inc[4][3], w0 = 0, w1 = 0, w2s = 0;
-            {
-                uint32_t pp = lower ? prev_in_wave : carry;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    pl[j] = pp;
-                    const uint32_t q = (pp * 11u) >> 5;
-                    sh[j] = 10u * (pp - 3u * q);
-                    const uint32_t one = coded[j] ? 1u << sh[j] : 0u;
-                    inc[j][0] = q == 0 ? one : 0u; inc[j][1] = q == 1 ? one : 0u; inc[j][2] = q == 2 ? one : 0u;
-                    w0 += inc[j][0]; w1 += inc[j][1]; w2s += inc[j][2];
-                    pp = coded[j] ? nl[j] : pp;
-                }
-            }
-            const uint32_t x0s = wave_scan_incl(w0), x1s = wave_scan_incl(w1), x2s = wave_scan_incl(w2s);
-            {
-                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x0s, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)x1s, 63),
-                               t2 = (uint32_t)__builtin_amdgcn_readlane((int)x2s, 63);
-                const uint32_t word = myq == 0 ? t0 : (myq == 1 ? t1 : t2);
-                if (lane < 9) s_wave_cnt[wv][lane] = (word >> mysh) & 1023u;
-            }
-            __syncthreads();  // (B) per-wave context counts visible
-            if (lane < 9) {
-                uint32_t base = s_run_cnt[lane];
-                for (uint32_t w = 0; w < wv; w++) base += s_wave_cnt[w][lane];
-                s_base[wv][lane] = base;
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t e0 = x0s - w0, e1 = x1s - w1, e2 = x2s - w2s;
-            unsigned __int128 frame = 0;
-            uint32_t pos = (run_bits & 31) + bit_base + (incl - lane_len);
-            const uint32_t wi = pos >> 5;
-            pos &= 31;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (coded[j]) {
-                    const uint32_t e = inc[j][0] ? e0 : (inc[j][1] ? e1 : e2);
-                    const uint32_t rank = (e >> sh[j]) & 1023u;
-                    sc[pl[j] * cap + s_base[wv][pl[j]] + rank] = (uint8_t)nl[j];
-                }
-                e0 += inc[j][0]; e1 += inc[j][1]; e2 += inc[j][2];
-                const uint32_t n1 = nl[j] & 15u;
-                const uint32_t v = len[j] ? ((((r4 >> (8 * j)) & 255u) << (2 * n1)) | (((g4 >> (8 * j)) & 255u) << n1) | ((b4 >> (8 * j)) & 255u)) : 0u;
-                frame |= (unsigned __int128)v << ((128u - pos - len[j]) & 127u);
-                pos += len[j];
-            }
-            {
-                const uint32_t f0 = (uint32_t)(frame >> 96), f1 = (uint32_t)(frame >> 64), f2 = (uint32_t)(frame >> 32), f3 = (uint32_t)frame;
-                if (f0) atomicOr(&s_bits[wi], f0);
-                if (f1) atomicOr(&s_bits[wi + 1], f1);
-                if (f2) atomicOr(&s_bits[wi + 2], f2);
-                if (f3) atomicOr(&s_bits[wi + 3], f3);
-            }
-            __syncthreads();  // (C) bit window complete
-
-            const uint32_t nfull = ((run_bits & 31) + bits_total) >> 5;
-            uint32_t keep[ST_ROUNDS], carry_word = 0;
-#pragma unroll
-            for (int k = 0; k < ST_ROUNDS; k++) { const uint32_t j = tid + k * ST_THREADS; keep[k] = j < (uint32_t)ST_WORDS ? s_bits[j] : 0u; }
-            if (tid == 0) carry_word = s_bits[nfull];
-            uint32_t tot_c = 0;
-            if (tid < 9) { for (int w = 0; w < ST_WAVES; w++) tot_c += s_wave_cnt[w][tid]; }
-            __syncthreads();  // (D) everyone has read the window / counts
-#pragma unroll
-            for (int k = 0; k < ST_ROUNDS; k++) {
-                const uint32_t j = tid + k * ST_THREADS;
-                if (j < nfull) kw[wbase + j] = keep[k];
-                if (j < (uint32_t)ST_WORDS) s_bits[j] = j == 0 ? carry_word : 0u;
-            }
-            if (tid < 9) s_run_cnt[tid] += tot_c;
-            run_bits += bits_total; wbase += nfull; run_pl = new_run_pl;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t words = wbase;
-        if (run_bits & 31) { kw[wbase] = s_bits[0]; words++; }  // BITSTREAM_END: tail is already left-aligned
-        k_n[tile] = words;
-    }
-    if (tid < 9) ctx_n[(uint64_t)tile * 9 + tid] = s_run_cnt[tid];
 }
 
 }  // namespace xpng

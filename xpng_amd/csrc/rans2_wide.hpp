@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     const uint8_t *in;
     uint32_t n, nominalN;
     int pb;
-    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
+    if (c < 9) { in = sc + off_ctx(t.n, ctx_n + (uint64_t)tile * 9, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
     uint32_t *out = reinterpret_cast<uint32_t *>(sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c));
     WPrep *p = prep + (uint64_t)tile * 10 + c;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     uint8_t *sc = scratch + t->sbase;
     WPrep *p = prep + (uint64_t)tile * 10 + c;
     live = live && p->kind == 1;
-    const uint8_t *in = BIG ? planes + 4 * plane_stride + t->pbase : sc + off_ctx(t->n, (int)c);  // 16-byte aligned; symbol i at in[i + SH]
+    const uint8_t *in = BIG ? planes + 4 * plane_stride + t->pbase : sc + off_ctx(t->n, ctx_n + (uint64_t)tile * 9, BIG ? 0 : (int)c);  // 16-byte aligned; symbol i at in[i + SH]
     const uint32_t n = !live ? 0 : BIG ? t->n - 1 : ctx_n[(uint64_t)tile * 9 + c];
     const uint32_t mysteps = (n + 1 - par) >> 1;  // state0 codes ceil(n/2) symbols, state1 floor(n/2)
     uint32_t T = mysteps, Tmin = live ? mysteps : 0u;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_rans2_finish(const TileDesc *__restrict_
     const uint8_t *in;
     uint32_t n;
     int pb;
-    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; pb = 12; }
+    if (c < 9) { in = sc + off_ctx(t.n, ctx_n + (uint64_t)tile * 9, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; pb = 15; }
     uint8_t *out8 = sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c);
     uint32_t *out = reinterpret_cast<uint32_t *>(out8);

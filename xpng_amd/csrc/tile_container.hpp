@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict_
     const uint8_t *in;
     uint32_t n, nominalN;
     int pb;
-    if (c < 9) { in = sc + off_ctx(t.n, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
+    if (c < 9) { in = sc + off_ctx(t.n, ctx_n + (uint64_t)tile * 9, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
     const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c), hist, cum, tab,
                                            dbg ? dbg + ((uint64_t)tile * 10 + c) * 8 : nullptr);

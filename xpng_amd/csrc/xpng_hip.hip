@@ -110,10 +110,7 @@ struct xpnghip_ctx {
     std::vector<TileDesc> tiles;  // the N tiles of ONE image (host copy); the device table has B * N entries
     uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
     TileDesc *d_tiles = nullptr;
-    uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (4 or 5 symbol planes) and d_scratch (level-1 stream scratch): allocated on first use
-    uint8_t *d_arena = nullptr;                         // decode planes of a context that never encoded at level 1 (else they live inside d_scratch)
-    uint8_t *d_aplane = nullptr;        // alpha symbol plane of the fused form (XPNG_FUSED): allocated on first use
-    const uint8_t *alpha_src = nullptr; // where the last encode left its alpha symbols (debug_fetch 5)
+    uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (4 or 5 symbol planes) and d_scratch (level-1 stream scratch = the decode's planes): allocated on first use
     uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
     uint64_t *d_off = nullptr, *d_totals = nullptr, *d_dbg = nullptr;
     uint64_t *d_blob_len = nullptr;       // decode: B blob lengths
@@ -175,7 +172,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_aplane, c->d_scratch, c->d_arena, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
+    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_blob_in, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
                     c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -225,11 +222,8 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         c->ws_bytes += (bytes);                                                                    \
     } while (0)
     ALLOC(c->d_tiles, VN * sizeof(TileDesc));
-    // (d_aplane, the alpha symbol plane of the FUSED form, is allocated on its first use: ensure_aplane - 1 B/px the default form
-    //  never touches, 1.07 GB per 64-image context of 4096^2 rasters)
-    // (the level-1 stream scratch, 15.5 B/px, is allocated by the first level-1 encode: ensure_scratch; the decode planes, 8 B/px,
-    //  live inside it when it exists and in an allocation of their own otherwise: ensure_arena.  A context that only ever codes
-    //  level 2 - whose own scratch is 40 B/px - does not pay for the level-1 streams: 60 -> 51.5 B/px with the four-plane RGB form)
+    // (the stream scratch - 7.5 B/px for a level-1 encode, 8 B/px as the decode's symbol / residual planes: one buffer of the larger
+    //  size - and the symbol planes, 4 or 5 B/px, are allocated by the first call that needs them: ensure_scratch, ensure_planes)
     ALLOC(c->d_sums, VN * 16);
     ALLOC(c->d_ctx_n, VN * 9 * 4);
     ALLOC(c->d_k_n, VN * 4);
@@ -323,30 +317,26 @@ static const uint32_t *order_for(const xpnghip_ctx *c, uint32_t t0, uint32_t t1)
     return (t0 == c->r0 && t1 == c->r1 && !probe_env("XPNG_IMAGE_MAJOR")) ? c->d_order : nullptr;
 }
 
-// the five symbol planes of the unfused form (BASELINE config-2 entry, mode 2, XPNG_UNFUSED): 5 B/px, allocated on first use
+// Level-1 stream scratch (k, block slots, context streams: 7.5 B/px, common.hpp) and the decode's symbol / residual planes
+// (8 B/px: DecodeWs::arena) are ONE buffer: a context's encode intermediates are dead by the time the same context decodes.
+static uint64_t scratch_bytes(const xpnghip_ctx *c) {
+    const uint64_t enc = c->scratch_img * c->B + 8192, dec = 8 * c->plane_stride + (2u << 20);
+    return enc > dec ? enc : dec;
+}
 static int ensure_scratch(xpnghip_ctx *c) {
     if (c->d_scratch) return 0;
-    const uint64_t bytes = c->scratch_img * c->B + 8192;
+    const uint64_t bytes = scratch_bytes(c);
     HIPCHK(hipMalloc((void **)&c->d_scratch, bytes));
     c->ws_bytes += bytes;
     return 0;
 }
-// where the decode keeps its symbol / residual planes (DecodeWs::arena): chosen at the context's first decode
 static int ensure_arena(xpnghip_ctx *c) {
     if (c->dec.arena) return 0;
-    if (c->d_scratch) { c->dec.arena = c->d_scratch; c->dec.arena_bytes = c->scratch_img * c->B + 8192; return 0; }
-    const uint64_t bytes = 8 * c->plane_stride + (2u << 20);
-    HIPCHK(hipMalloc((void **)&c->d_arena, bytes));
-    c->ws_bytes += bytes;
-    c->dec.arena = c->d_arena; c->dec.arena_bytes = bytes;
+    if (ensure_scratch(c)) return 1;
+    c->dec.arena = c->d_scratch; c->dec.arena_bytes = scratch_bytes(c);
     return 0;
 }
-static int ensure_aplane(xpnghip_ctx *c) {
-    if (c->d_aplane) return 0;
-    HIPCHK(hipMalloc((void **)&c->d_aplane, c->plane_stride + 8192));  // + slack: LDS-ring staging reads whole 1 KB units
-    c->ws_bytes += c->plane_stride + 8192;
-    return 0;
-}
+// the symbol planes (nl, r, g, b, + alpha symbols for RGBA): allocated on first use
 static int ensure_planes(xpnghip_ctx *c) {
     if (c->d_planes) return 0;
     const uint64_t np = c->pxsz == 4 ? 5 : 4;  // nl, r, g, b (+ alpha symbols)
@@ -426,63 +416,37 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     const uint64_t bpr = c->W * PXSZ;
     uint32_t max_w = 0;
     for (uint32_t i = t0; i < t1; i++) max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w;
-    // Two forms of transform + routing, same bytes.  Default: k_m1_transform_* -> five symbol planes -> k_m1_streams.
-    // XPNG_FUSED=1: chooser, then k_m1_fused (the nl / r / g / b planes never exist: 4 B/px less workspace, 3.7 B/px less HBM
-    // traffic; the alpha symbols come from k_alpha_syms).  Measured (64 rasters, 5 slots): fused 31.5 Gpx/s and 137 GB, unfused
-    // 33.3 Gpx/s and 157 GB - one long-lived 28 KB workgroup per tile sits worse beside the chain kernels of the other slots than
-    // the short transform kernel plus a lighter routing kernel do - so the faster form is the default and the leaner one a switch.
-    const bool fused = max_w <= TR_MAXW && getenv("XPNG_FUSED") && !getenv("XPNG_UNFUSED");
     const bool narrow = getenv("XPNG_NARROW_RANS") || (total * c->spt <= 2048 && !getenv("XPNG_WIDE_RANS"));
     const bool small_wg = (uint64_t)total * c->spt > 2048 && !probe_env("XPNG_BIG_BLOCKS");
-    // RGBA, fused: the alpha symbols come from a small pass of their own (they do not depend on the predictor choice), so the
-    // alpha chains start before the chooser has even run; XPNG_ALPHA_IN_FUSED=1: k_m1_fused writes them (one raster read less,
-    // the alpha chains start ~5 ms later: measured 16.0 against 13.7 ms per 64 images at 3 slots)
-    const bool alpha_pass = fused && PXSZ == 4 && !probe_env("XPNG_ALPHA_IN_FUSED");
     static const size_t pad_tr = probe_pad("XPNG_PAD_TR"), pad_st = probe_pad("XPNG_PAD_ST"), pad_ga = probe_pad("XPNG_PAD_GA");
-    if ((fused ? ensure_aplane(c) : ensure_planes(c)) || ensure_scratch(c)) return 1;  // (before their address is taken below)
-    XPNG_REQUIRE(fused ? (const void *)c->d_aplane : (const void *)c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
+    if (ensure_planes(c) || ensure_scratch(c)) return 1;  // (before their address is taken below)
+    XPNG_REQUIRE(c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
                  c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wF, c->h_total);
-    const uint8_t *planesA = fused ? c->d_aplane - 4 * c->plane_stride : c->d_planes;  // the alpha plane as "plane 4" of a five-plane base
+    const uint8_t *planesA = c->d_planes;
     const bool alpha_side = !narrow && PXSZ == 4;
     if (alpha_side && !c->enc_side) {
         HIPCHK(chain_stream_create(&c->enc_side));
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
     }
-    auto alpha_branch = [&](hipStream_t as) -> int {  // alpha plane -> tables -> chains, on the side stream
+    // (A fused transform + routing kernel - no nl / r / g / b planes, 3.7 B/px less HBM traffic - existed through round 3 behind
+    //  XPNG_FUSED: one long-lived 28 KB workgroup per tile, 12 % slower in the pipeline every time it was measured, and it cannot
+    //  know the stream lengths before it routes.  Removed with the worst-case stream layout; git history has it.)
+    if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr)) return 1;
+    // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
+    // preparation and the chains themselves run on their own stream behind the transform
+    if (alpha_side) {
+        HIPCHK(hipEventRecord(c->ev_enc_fork, s));
+        HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
+        hipStream_t as = c->enc_side;
         if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
         if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
-        return 0;
-    };
-    if (alpha_pass) {
-        uint32_t max_n = 0;
-        for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
-        const uint32_t bpt = (max_n + 1024 * TG_REPS - 1) / (1024 * TG_REPS);
-        const TileSel isel{t0, cnt, (uint32_t)c->tiles.size(), nimg, nullptr};  // image-major: a streaming pass over the rasters
-        hipStream_t as = alpha_side ? c->enc_side : s;
-        if (alpha_side) { HIPCHK(hipEventRecord(c->ev_enc_fork, s)); HIPCHK(hipStreamWaitEvent(as, c->ev_enc_fork, 0)); }
-        k_alpha_syms<<<total * bpt, 256, 0, as>>>(c->d_in_ptrs, bpr, c->d_tiles, isel, bpt, c->d_aplane);
-        if (alpha_side && alpha_branch(as)) return 1;
     }
-    if (fused) {
-        if (launch_chooser<PXSZ>(c, nimg, t0, t1, s)) return 1;
-        if (small_wg) k_m1_fused<PXSZ, 256><<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * PXSZ, c->d_tiles, sel, c->d_sums, alpha_pass ? nullptr : c->d_aplane, c->d_scratch, c->d_ctx_n, c->d_k_n);
-        else k_m1_fused<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->W * c->H * PXSZ, c->d_tiles, sel, c->d_sums, alpha_pass ? nullptr : c->d_aplane, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    } else if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr)) return 1;
-    c->alpha_src = planesA + 4 * c->plane_stride;
-    // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
-    // preparation and the chains themselves run on their own stream (started above when the alpha pass made the plane; here, behind
-    // the kernel that wrote it, otherwise)
-    if (alpha_side && !alpha_pass) {
-        HIPCHK(hipEventRecord(c->ev_enc_fork, s));
-        HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
-        if (alpha_branch(c->enc_side)) return 1;
-    }
-    if (!fused) {
-        if (dbg_skip("streams")) {} else if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-        else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
-    }
+    // stream lengths (histogram of the nl plane) -> places of the nine context streams -> routing
+    if (!dbg_skip("count")) k_m1_count<<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_planes, c->d_ctx_n);
+    if (dbg_skip("streams")) {} else if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
+    else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     if (narrow) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
@@ -676,8 +640,6 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
         if (cap < 1) return -1;
         *(uint8_t *)out = pr;
         return 1;
-    } else if (what == 5 && c->alpha_src) {
-        src = c->alpha_src + t.pbase; bytes = t.n;
     } else if (what >= 1 && what <= 5) {
         if (!c->d_planes || (what == 5 && c->pxsz != 4)) return -1;  // the five planes exist after xpnghip_m1_transform_device (config-2 entry) or a mode-2 encode
         src = c->d_planes + (uint64_t)(what - 1) * c->plane_stride + t.pbase; bytes = t.n;
@@ -685,7 +647,7 @@ extern "C" int64_t xpnghip_debug_fetch(xpnghip_ctx *c, int what, uint64_t tile, 
         return -1;  // no level-1 encode has run on this context
     } else if (what >= 10 && what <= 18) {
         if (!d2h(tmp, c->d_ctx_n + tile * 9, 36)) return -1;
-        src = c->d_scratch + t.sbase + off_ctx(t.n, what - 10); bytes = tmp[what - 10];
+        src = c->d_scratch + t.sbase + off_ctx(t.n, tmp, what - 10); bytes = tmp[what - 10];
     } else if (what == 19) {
         if (!d2h(tmp, c->d_k_n + tile, 4)) return -1;
         src = c->d_scratch + t.sbase + off_kw(t.n); bytes = 4ull * tmp[0];
