@@ -545,15 +545,13 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
 //     len[c] = hist[c] - [c == nl of the last coded pixel] + [c == 0]            (all zero when the tile codes no pixel)
 // with hist = histogram of the nl plane over coded pixels.  One 256-thread workgroup per tile reads the plane once (16 pixels
 // per thread and step; nine 7-bit fields of a 64-bit accumulator, spilled into nine counters every 7 steps).
-__global__ __launch_bounds__(256) void k_m1_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint8_t *__restrict__ planes,
-                                                  uint32_t *__restrict__ ctx_n) {
-    const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
-    const TileDesc t = tiles[tile];
+// core: histogram of the tile's nl plane over coded pixels -> s_hist[9] (LDS), and s_last = (index of the last coded pixel + 1) << 4 |
+// its nl (0: the tile codes no pixel).  256-thread workgroup; both LDS objects are valid after the closing barrier.
+__device__ __forceinline__ void tile_nl_histogram(const TileDesc &t, const uint8_t *__restrict__ planes, uint32_t *s_hist, uint32_t *s_last) {
+    const uint32_t tid = threadIdx.x;
     const uint4 *pnl = reinterpret_cast<const uint4 *>(planes + t.pbase);  // (plane bases are multiples of 256; >= 192 bytes of slack behind a tile)
-    __shared__ uint32_t s_hist[9];
-    __shared__ uint32_t s_last;  // (index of the last coded pixel + 1) << 4 | its nl
     if (tid < 9) s_hist[tid] = 0;
-    if (tid == 0) s_last = 0;
+    if (tid == 0) *s_last = 0;
     __syncthreads();
     uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
     uint64_t acc = 0;
@@ -588,9 +586,17 @@ __global__ __launch_bounds__(256) void k_m1_count(const TileDesc *__restrict__ t
         uint32_t v = last;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
-        if ((tid & 63) == 0 && v) atomicMax(&s_last, v);
+        if ((tid & 63) == 0 && v) atomicMax(s_last, v);
     }
     __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_m1_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint8_t *__restrict__ planes,
+                                                  uint32_t *__restrict__ ctx_n) {
+    const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
+    const TileDesc t = tiles[tile];
+    __shared__ uint32_t s_hist[9];
+    __shared__ uint32_t s_last;
+    tile_nl_histogram(t, planes, s_hist, &s_last);
     if (tid < 9) {
         const uint32_t l = s_last;
         uint32_t len = s_hist[tid];

@@ -40,7 +40,8 @@ constexpr uint32_t M2_KIND_BAD = 9;  // tile failed validation: every kernel ski
 __global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const uint64_t *__restrict__ off,
                                const uint64_t *__restrict__ blob_len, uint32_t cnt, uint32_t total,
                                const TileDesc *__restrict__ tiles, TileSel sel, M2DecTile *__restrict__ info,
-                               M2Blk *__restrict__ blk, uint16_t *__restrict__ tabs, uint32_t *__restrict__ status) {
+                               M2Blk *__restrict__ blk, uint16_t *__restrict__ tabs, uint32_t *__restrict__ stream_n,
+                               uint32_t *__restrict__ status) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
     const uint32_t tile = vtile(sel, j);
@@ -52,6 +53,8 @@ __global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const u
     const uint32_t h0 = ok ? ld32u(d.blob) : 0, ty = h0 >> 24, L = h0 & 0xFFFFFF;
     ok = ok && L <= avail && L >= 8;
     M2Blk *mb = blk + (uint64_t)tile * M2_SLOTS;
+    uint32_t *sn = stream_n + (uint64_t)tile * M2_SLOTS;  // symbol counts of the tile's streams: where the decoded streams go (m2_off_stream)
+    for (uint32_t s = 0; s < M2_SLOTS; s++) sn[s] = 0;
     if (ty == 0) { d.kind = 0; ok = ok && L == 3 * t.n + 4; }
     else if (ty == 255) { d.kind = 4; ok = ok && L == 8; }
     else if ((ty >> 4) == 2) { d.kind = (ty & 8) ? 3 : 2; d.m = ty & 3; if (d.kind == 3) ok = ok && L == t.n + 4; }
@@ -66,6 +69,7 @@ __global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const u
         const uint64_t endbit = (uint64_t)(d.bsz - 4) * 8;
         uint64_t pos = d.kind == 1 ? 24 : 8;
         uint32_t o = 4 + d.bsz, coded = 0;
+        uint64_t room = 0;  // bytes of the stream region the streams read so far take
         const uint32_t s0 = d.kind == 1 ? 0 : 17, s1 = d.kind == 1 ? M2_STREAMS : 18;
         for (uint32_t s = s0; s < s1 && ok; s++) {
             const uint32_t Nnom = m2_nominal(s), pb = s >= 17 ? 15 : 14, rawBits = (uint32_t)bit_width(Nnom - 1);
@@ -75,9 +79,12 @@ __global__ void k_m2_dec_parse(const uint8_t *const *__restrict__ blobs, const u
             ok = type <= 4 && bsize >= (type == 0 ? 4u : 8u) && (uint64_t)o + bsize <= L && (type < 3 || bsize >= 24);
             if (!ok) break;
             const uint32_t w1 = type ? ld32u(d.blob + o + 4) : 0;
-            const uint32_t ncap = (s >= 11 && s < 17) ? 3 * t.n : t.n;  // stream capacity (m2_off_stream layout)
-            ok = (type == 1 ? (w1 & 0xFFFFFF) : w1) <= ncap;
+            const uint32_t ncap = (s >= 11 && s < 17) ? 3 * t.n : t.n;  // what the format allows a stream to hold
+            const uint32_t nsym = type == 1 ? (w1 & 0xFFFFFF) : w1;
+            room += m2_slot(type ? nsym : 0u);
+            ok = nsym <= ncap && room <= m2_streams_region(t.n);  // (the streams lie back to back, each in the room its length needs)
             if (!ok) break;
+            sn[s] = type ? nsym : 0u;
             M2Blk r{type, 0, o, 0};
             if (type == 1) { r.n = w1 & 0xFFFFFF; r.pbits = w1 >> 24; }
             else if (type == 2) { r.n = w1; r.pbits = (uint32_t)pos; pos += (uint64_t)w1 * rawBits; }
@@ -109,7 +116,7 @@ template <int MAXPB>
 __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                      uint32_t s_first, uint32_t s_count, const M2Blk *__restrict__ blk,
                                                      const uint16_t *__restrict__ tabs, uint8_t *__restrict__ scratch2,
-                                                     const uint64_t *__restrict__ sbase2) {
+                                                     const uint64_t *__restrict__ sbase2, const uint32_t *__restrict__ stream_n) {
     // per group of 8 slots: (F | cum << 16, symbol) of the symbol owning slot (g << 3): one LDS read resolves a cold slot whose
     // group lies inside one symbol's range, else a short forward scan over fc[] follows (as k_rans2_decode)
     __shared__ uint2 coarse[1 << (MAXPB - 3)];
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
     const uint32_t tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
     const M2Blk mb = blk[(uint64_t)tile * M2_SLOTS + slot];
-    uint8_t *out = scratch2 + sbase2[tile] + m2_off_stream(t.n, slot);
+    uint8_t *out = scratch2 + sbase2[tile] + m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot);
     const uint32_t type = sgpr(mb.type), n = sgpr(mb.n);
     const uint32_t Nnom = m2_nominal(slot);
     const int pb = slot >= 17 ? 15 : 14;
@@ -284,14 +291,14 @@ __global__ __launch_bounds__(64) void k_rans1_decode(const M2DecTile *__restrict
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_m2_dec_walk(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
-                                                    uint8_t *__restrict__ nlseq) {
+                                                    const uint32_t *__restrict__ stream_n, uint8_t *__restrict__ nlseq) {
     const uint32_t j = blockIdx.x, lane = threadIdx.x & 63;
     const M2DecTile d = info[j];
     if (d.kind != 1) return;
     const uint32_t tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
-    // (the nine context streams start at multiples of 256 bytes inside the tile's scratch: the scalar-unit walk applies)
-    ctx_walk_salu(scratch2 + sbase2[tile], lane < 9 ? (uint32_t)m2_off_stream(t.n, lane) : 0, sgpr(d.coded), nlseq + t.pbase);
+    // (the nine context streams start at multiples of 64 bytes inside the tile's scratch: the scalar-unit walk applies)
+    ctx_walk_salu(scratch2 + sbase2[tile], lane < 9 ? (uint32_t)m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, lane) : 0, sgpr(d.coded), nlseq + t.pbase);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -299,7 +306,8 @@ __global__ __launch_bounds__(64) void k_m2_dec_walk(const M2DecTile *__restrict_
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                        const uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
-                                                       const uint8_t *__restrict__ nlseq, uint32_t *__restrict__ resid) {
+                                                       const uint32_t *__restrict__ stream_n, const uint8_t *__restrict__ nlseq,
+                                                       uint32_t *__restrict__ resid) {
     const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const M2DecTile d = info[j];
     if (d.kind != 1 && d.kind != 2) return;
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__res
     const uint8_t *sc = scratch2 + sbase2[tile];
     uint32_t *rs = resid + t.pbase;
     if (d.kind == 2) {
-        const uint8_t *st = sc + m2_off_stream(t.n, 17);
+        const uint8_t *st = sc + m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, 17);
         for (uint32_t i = tid; i < t.n; i += THREADS) {
             uint32_t w = 0;
             if (i) { const uint32_t v = (uint32_t)zz_dec(st[i - 1]) & 255u; w = v | (v << 8) | (v << 16) | (1u << 24); }
@@ -318,8 +326,9 @@ __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__res
     }
     const uint8_t *nls = nlseq + t.pbase;
     const int useG = d.m & 1;
-    __shared__ uint32_t s_wave[THREADS / 64][9], s_run[9];
+    __shared__ uint32_t s_wave[THREADS / 64][9], s_run[9], s_off[9];
     if (tid < 9) s_run[tid] = 0;
+    if (tid >= 1 && tid < 9) s_off[tid] = (uint32_t)m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, 8 + tid);  // class stream of nl = tid
     __syncthreads();
     const uint64_t lt = lanemask_lt();
     for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__res
                 if (nl) {
                     uint32_t base = s_run[nl];
                     for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave[w2][nl];
-                    const uint8_t *st = sc + m2_off_stream(t.n, 8 + nl);
+                    const uint8_t *st = sc + s_off[nl];
                     const uint32_t k = base + rank;
                     uint32_t zr, zg, zb;
                     if (nl == 1) { const uint32_t v = st[k]; zr = v >> 2; zg = (v >> 1) & 1; zb = v & 1; }
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(64) void k_m2_dec_recon_band(const M2DecTile *__res
 
 inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t total, const M2DecTile *d_info2, const TileDesc *d_tiles,
                           TileSel sel, const M2Blk *d_blk2, const uint16_t *d_tabs2, uint8_t *d_scratch2, const uint64_t *d_sbase2,
-                          hipStream_t s, std::string &err);  // rans1_wide_dec.hpp
+                          const uint32_t *d_stream_n2, hipStream_t s, std::string &err);  // rans1_wide_dec.hpp
 
 // Launch the mode-2 decode of tiles [t0, t1) of every image of the batch (RGB only).
 inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t plane_total, const TileDesc *d_tiles, uint64_t W,
@@ -455,24 +464,24 @@ inline int decode_m2_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                             const uint8_t *const *d_blob_ptrs, const uint64_t *d_blob_len, uint32_t *d_status,
                             const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, M2DecTile *d_info2, M2Blk *d_blk2, uint16_t *d_tabs2, uint8_t *d_scratch2,
-                            const uint64_t *d_sbase2, hipStream_t s, std::string &err) {
+                            const uint64_t *d_sbase2, uint32_t *d_stream_n2, hipStream_t s, std::string &err) {
     const uint32_t cnt = t1 - t0, total = B * cnt;
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, nullptr};
     if (decode_ws_prepare(ws, B, n_tiles, plane_total, tile_off, t0, total, s, err, d_blob_ptrs, d_blob_len)) return 1;
-    if (!ws.d_off || !ws.d_nlseq || !ws.d_resid || !d_info2 || !d_blk2 || !d_tabs2 || !d_scratch2 || !d_sbase2 || !d_tiles || !d_blob_ptrs || !d_raster_ptrs) {
+    if (!ws.d_off || !ws.d_nlseq || !ws.d_resid || !d_info2 || !d_blk2 || !d_tabs2 || !d_scratch2 || !d_sbase2 || !d_stream_n2 || !d_tiles || !d_blob_ptrs || !d_raster_ptrs) {
         err = "internal error: a mode-2 decode workspace buffer was never allocated";  // (a null pointer in a kernel is a GPU fault = abort())
         return 1;
     }
     const uint64_t bpr = W * 3;
     if (hipMemsetAsync(d_blk2, 0, (uint64_t)B * n_tiles * M2_SLOTS * sizeof(M2Blk), s) != hipSuccess) { err = "memset failed"; return 1; }
-    k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2, d_status);
+    k_m2_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, d_tiles, sel, d_info2, d_blk2, d_tabs2, d_stream_n2, d_status);
     if (getenv("XPNG_NARROW_RANS") || ((uint64_t)total * M2_STREAMS <= 2048 && !getenv("XPNG_WIDE_RANS"))) {
-        k_rans1_decode<14><<<total * M2_STREAMS, 64, 0, s>>>(d_info2, d_tiles, sel, 0, M2_STREAMS, d_blk2, d_tabs2, d_scratch2, d_sbase2);
-        k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2);  // gray tiles
-    } else if (m2_wide_decode(ws, B, n_tiles, total, d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, s, err)) return 1;
-    k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq);
-    if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_dec_resid<256><<<total, 256, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
-    else k_m2_dec_resid<1024><<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, ws.d_nlseq, ws.d_resid);
+        k_rans1_decode<14><<<total * M2_STREAMS, 64, 0, s>>>(d_info2, d_tiles, sel, 0, M2_STREAMS, d_blk2, d_tabs2, d_scratch2, d_sbase2, d_stream_n2);
+        k_rans1_decode<15><<<total, 64, 0, s>>>(d_info2, d_tiles, sel, 17, 1, d_blk2, d_tabs2, d_scratch2, d_sbase2, d_stream_n2);  // gray tiles
+    } else if (m2_wide_decode(ws, B, n_tiles, total, d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, d_stream_n2, s, err)) return 1;
+    k_m2_dec_walk<<<total, 64, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, d_stream_n2, ws.d_nlseq);
+    if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_dec_resid<256><<<total, 256, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, d_stream_n2, ws.d_nlseq, ws.d_resid);
+    else k_m2_dec_resid<1024><<<total, 1024, 0, s>>>(d_info2, d_tiles, sel, d_scratch2, d_sbase2, d_stream_n2, ws.d_nlseq, ws.d_resid);
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
     const bool wide_recon = !getenv("XPNG_NARROW_RANS") && ((uint64_t)total * M2_STREAMS > 2048 || getenv("XPNG_WIDE_RANS")) && max_w <= RB_MAXW && !probe_env("XPNG_WAVEFRONT_RECON");

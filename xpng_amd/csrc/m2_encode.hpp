@@ -29,13 +29,19 @@ __host__ __device__ inline uint32_t m2_nominal(uint32_t s) {  // alphabet of str
     const uint32_t v = s - 8;  // class 1..8
     return v < 3 ? (1u << (3 * v)) : (1u << v);
 }
-// per-tile scratch layout for mode 2 (bytes, relative to the tile's m2 scratch base)
-__host__ __device__ inline uint64_t m2_small(uint32_t n) { return rup((uint64_t)n + 64, 256); }       // ctx / class 1,2 / gray streams
-__host__ __device__ inline uint64_t m2_big(uint32_t n) { return rup(3ull * n + 64, 256); }            // class >= 3 streams
-__host__ __device__ inline uint64_t m2_off_stream(uint32_t n, uint32_t s) {
-    if (s < 11) return (uint64_t)s * m2_small(n);                                   // ctx 0..8, class 1, 2
-    if (s < 17) return 11 * m2_small(n) + (uint64_t)(s - 11) * m2_big(n);           // class 3..8
-    return 11 * m2_small(n) + (uint64_t)(s - 17) * m2_small(n);                     // gray candidates overlay class >= 3
+// per-tile scratch layout for mode 2 (bytes, relative to the tile's m2 scratch base):
+//   [the symbol streams, back to back][block slots][table pieces][bit stream b]
+// The stream lengths are known before a symbol is written (k_m2_count: a histogram of the nl plane, as for mode 1; a gray tile's
+// four candidates hold n - 1 symbols each) - in a decode they are the block headers' symbol counts - so every stream gets the
+// room its length needs: a colour tile's nine context streams share n - 1 symbols, its eight class streams at most 3 (n - 1),
+// and the region is 4 n bytes + slack instead of 29 n (nine + two streams of n and six of 3 n in rounds 1-3).
+// cnt: the tile's M2_SLOTS stream lengths (stream_n + tile * M2_SLOTS; absent streams 0).
+__host__ __device__ inline uint64_t m2_slot(uint32_t m) { return rup((uint64_t)m + 32, 64); }
+__host__ __device__ inline uint64_t m2_streams_region(uint32_t n) { return rup(4ull * n + 21 * 96, 256); }
+__host__ __device__ inline uint64_t m2_off_stream(uint32_t, const uint32_t *cnt, uint32_t s) {
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < s; i++) o += m2_slot(cnt[i]);
+    return o;
 }
 // Block slots (the words a stream's rANS chain emits: <= 15 bits per symbol, + states and slack) are laid out back to back, each
 // sized by ITS stream's symbol count cnt[k] (known once k_m2_streams / k_m2_gray_syms have run), not by the stream's capacity: a
@@ -44,13 +50,13 @@ __host__ __device__ inline uint64_t m2_off_stream(uint32_t n, uint32_t s) {
 __host__ __device__ inline uint64_t m2_blk_cap(uint32_t m) { return rup(2ull * m + 512, 256); }
 __host__ __device__ inline uint64_t m2_blk_region(uint32_t n) { return rup(8ull * n + 21 * 768, 256); }
 __host__ __device__ inline uint64_t m2_off_blk(uint32_t n, const uint32_t *cnt, uint32_t s) {  // cnt: the tile's M2_SLOTS stream lengths
-    uint64_t o = 11 * m2_small(n) + 6 * m2_big(n);
+    uint64_t o = m2_streams_region(n);
     if (s >= 17) return o + (uint64_t)(s - 17) * m2_blk_cap(n);  // gray candidates (a gray tile has no colour blocks)
     for (uint32_t k = 0; k < s; k++) o += m2_blk_cap(cnt[k]);
     return o;
 }
 __host__ __device__ inline uint64_t m2_off_piece(uint32_t n, uint32_t s) {  // table bits of stream s: <= 256 * 16 bits
-    return 11 * m2_small(n) + 6 * m2_big(n) + m2_blk_region(n) + (uint64_t)s * 640;
+    return m2_streams_region(n) + m2_blk_region(n) + (uint64_t)s * 640;
 }
 __host__ __device__ inline uint64_t m2_off_bits(uint32_t n) { return m2_off_piece(n, M2_SLOTS); }
 __host__ __device__ inline uint64_t m2_bits_cap(uint32_t n) { return rup(3ull * n + 21 * 640 + 256, 256); }
@@ -90,6 +96,34 @@ __global__ __launch_bounds__(256) void k_m2_classify(const uint8_t *const *__res
 }
 
 // --------------------------------------------------------------------------------------------------
+// stream lengths of every tile, before anything is routed (the layout above needs them): a colour tile's nine context streams as
+// in k_m1_count, its class stream v holds one symbol (v = 1, 2) or three (v >= 3) per coded pixel with nl = v; a gray tile's four
+// candidate streams hold n - 1 symbols each; everything else 0.   grid = tiles, block = 256.
+__global__ __launch_bounds__(256) void k_m2_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
+                                                  const uint8_t *__restrict__ planes, uint32_t *__restrict__ stream_n) {
+    const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
+    const TileDesc t = tiles[tile];
+    const uint32_t f = flags[tile];
+    uint32_t *sn = stream_n + (uint64_t)tile * M2_SLOTS;
+    if ((f & (M2F_NOT_SINGLE | M2F_NOT_GRAY)) != (M2F_NOT_SINGLE | M2F_NOT_GRAY)) {  // single colour or gray
+        const bool gray = (f & M2F_NOT_SINGLE) && !(f & M2F_NOT_GRAY);
+        if (tid < M2_SLOTS) sn[tid] = gray && tid >= 17 ? t.n - 1 : 0u;
+        return;
+    }
+    __shared__ uint32_t s_hist[9];
+    __shared__ uint32_t s_last;
+    tile_nl_histogram(t, planes, s_hist, &s_last);
+    if (tid < 9) {
+        const uint32_t l = s_last;
+        uint32_t len = s_hist[tid];
+        if (l) len = len - ((l & 15u) == tid ? 1u : 0u) + (tid == 0 ? 1u : 0u);
+        sn[tid] = len;
+        if (tid >= 1) sn[8 + tid] = s_hist[tid] * (tid >= 3 ? 3u : 1u);
+    }
+    if (tid >= 17 && tid < M2_SLOTS) sn[tid] = 0;
+}
+
+// --------------------------------------------------------------------------------------------------
 // routing for colour tiles: context streams by pl (as k_m1_streams) and class streams by nl.  grid = tiles, block = THREADS
 // (1024 for one image: the tile's latency; 256 for batches: four barriers per 256-pixel step cost less among 4 waves than among 16,
 // and eight workgroups share a CU instead of two).
@@ -97,7 +131,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
-                                                     uint32_t *__restrict__ stream_n) {
+                                                     const uint32_t *__restrict__ stream_n) {
     const uint32_t tile = vtile(sel, blockIdx.x);
     const TileDesc t = tiles[tile];
     if ((flags[tile] & (M2F_NOT_SINGLE | M2F_NOT_GRAY)) != (M2F_NOT_SINGLE | M2F_NOT_GRAY)) return;  // single colour or gray
@@ -106,9 +140,11 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
     const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;
     uint8_t *sc = scratch2 + sbase2[tile];
     __shared__ uint32_t s_run_ctx[9], s_run_cls[9];
+    __shared__ uint32_t s_off[17];  // places of the 17 streams (their lengths are known: k_m2_count)
     __shared__ uint32_t s_wave_ctx[THREADS / 64][9], s_wave_cls[THREADS / 64][9];
     __shared__ uint32_t s_wave_last[THREADS / 64];
     if (tid < 9) { s_run_ctx[tid] = 0; s_run_cls[tid] = 0; }
+    if (tid < 17) s_off[tid] = (uint32_t)m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, tid);
     __syncthreads();
     uint32_t run_pl = 0;
     const uint64_t lt = lanemask_lt();
@@ -149,11 +185,11 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
         if (coded) {
             uint32_t base = s_run_ctx[pl];
             for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave_ctx[w2][pl];
-            sc[m2_off_stream(t.n, pl) + base + ctx_rank] = (uint8_t)nlv;
+            sc[s_off[pl] + base + ctx_rank] = (uint8_t)nlv;
             if (nlv) {
                 uint32_t cb = s_run_cls[nlv];
                 for (uint32_t w2 = 0; w2 < wv; w2++) cb += s_wave_cls[w2][nlv];
-                uint8_t *dst = sc + m2_off_stream(t.n, 8 + nlv);
+                uint8_t *dst = sc + s_off[8 + nlv];
                 const uint32_t zr = pr_[i], zg = pg[i], zb = pb[i];
                 if (nlv == 1) dst[cb + cls_rank] = (uint8_t)((zr << 2) | (zg << 1) | zb);        // libxpng.c:37
                 else if (nlv == 2) dst[cb + cls_rank] = (uint8_t)((zr << 4) | (zg << 2) | zb);   // libxpng.c:38
@@ -167,8 +203,6 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
         run_pl = new_run_pl;
         __syncthreads();
     }
-    if (tid < 9) stream_n[(uint64_t)tile * M2_SLOTS + tid] = s_run_ctx[tid];
-    if (tid >= 1 && tid < 9) stream_n[(uint64_t)tile * M2_SLOTS + 8 + tid] = s_run_cls[tid] * (tid >= 3 ? 3u : 1u);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -177,14 +211,14 @@ constexpr uint32_t M2_GRAY_REPS = 16;
 __global__ __launch_bounds__(256) void k_m2_gray_syms(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                       const TileDesc *__restrict__ tiles, TileSel sel, uint32_t bpt,
                                                       const uint32_t *__restrict__ flags, uint8_t *__restrict__ scratch2,
-                                                      const uint64_t *__restrict__ sbase2, uint32_t *__restrict__ stream_n) {
+                                                      const uint64_t *__restrict__ sbase2, const uint32_t *__restrict__ stream_n) {
     const uint32_t tile = vtile(sel, blockIdx.x / bpt), chunk = blockIdx.x % bpt;
     const TileDesc t = tiles[tile];
     const uint32_t f = flags[tile];
     if (!(f & M2F_NOT_SINGLE) || (f & M2F_NOT_GRAY)) return;  // only gray, not single-colour, tiles
     const uint8_t *raster = rasters[t.img];
     uint8_t *sc = scratch2 + sbase2[tile];
-    if (chunk == 0 && threadIdx.x < 4) stream_n[(uint64_t)tile * M2_SLOTS + 17 + threadIdx.x] = t.n - 1;
+    const uint64_t o17 = m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, 17), gs = m2_slot(t.n - 1);  // (k_m2_count set the four lengths to n - 1)
     for (uint32_t rep = 0; rep < M2_GRAY_REPS; rep++) {  // (4096 pixels per workgroup: a colour image launches these to find nothing)
     const uint32_t i = (chunk * M2_GRAY_REPS + rep) * 256 + threadIdx.x + 1;  // pixel 1..n-1 -> symbol i-1
     if (i >= t.n) return;
@@ -198,10 +232,10 @@ __global__ __launch_bounds__(256) void k_m2_gray_syms(const uint8_t *const *__re
         const int L = p[-3], U = *(p - bpr), UL = *(p - bpr - 3);
         s0 = zz_enc(v - L); s1 = zz_enc(v - U); s2 = zz_enc(v - pred_avg(L, U)); s3 = zz_enc(v - pred_grad(L, U, UL));
     }
-    sc[m2_off_stream(t.n, 17) + i - 1] = (uint8_t)s0;
-    sc[m2_off_stream(t.n, 18) + i - 1] = (uint8_t)s1;
-    sc[m2_off_stream(t.n, 19) + i - 1] = (uint8_t)s2;
-    sc[m2_off_stream(t.n, 20) + i - 1] = (uint8_t)s3;
+    sc[o17 + i - 1] = (uint8_t)s0;
+    sc[o17 + gs + i - 1] = (uint8_t)s1;
+    sc[o17 + 2 * gs + i - 1] = (uint8_t)s2;
+    sc[o17 + 3 * gs + i - 1] = (uint8_t)s3;
     }
 }
 
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(64) void k_rans1_encode(const TileDesc *__restrict_
     const bool single = !(f & M2F_NOT_SINGLE), gray = !single && !(f & M2F_NOT_GRAY);
     if (single || (gray != (slot >= 17))) return;  // colour tiles run slots 0..16, gray tiles 17..20
     uint8_t *sc = scratch2 + sbase2[tile];
-    const uint8_t *in = sc + m2_off_stream(t.n, slot);
+    const uint8_t *in = sc + m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot);
     const uint32_t n = sgpr(stream_n[(uint64_t)tile * M2_SLOTS + slot]);
     const uint32_t Nnom = m2_nominal(slot);
     const int pb = slot >= 17 ? 15 : 14;
@@ -427,7 +461,7 @@ __global__ void k_m2_select(const TileDesc *__restrict__ tiles, TileSel sel, uin
 __global__ __launch_bounds__(256) void k_m2_bits(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                  const TileDesc *__restrict__ tiles, TileSel sel, const M2Tile *__restrict__ mt,
                                                  const M2Blk *__restrict__ blk, uint8_t *__restrict__ scratch2,
-                                                 const uint64_t *__restrict__ sbase2) {
+                                                 const uint64_t *__restrict__ sbase2, const uint32_t *__restrict__ stream_n) {
     const uint32_t tile = vtile(sel, blockIdx.x);
     const TileDesc t = tiles[tile];
     const M2Tile r = mt[tile];
@@ -459,7 +493,7 @@ __global__ __launch_bounds__(256) void k_m2_bits(const uint8_t *const *__restric
             const M2Blk mb = b[slot];
             if (mb.type == 2) {  // raw symbols, rawBits each, MSB first (libxpng.c:251)
                 const uint32_t rb = mb.pbits / mb.n;
-                const uint8_t *st = sc + m2_off_stream(t.n, slot);
+                const uint8_t *st = sc + m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot);
                 uint32_t jsym = (a - o0) / rb;
                 for (;; jsym++) {
                     const uint32_t s0 = o0 + jsym * rb, s1 = s0 + rb;  // this symbol's bits in the stream

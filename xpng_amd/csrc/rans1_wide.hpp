@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_rans1_prep(const TileDesc *__restrict__ 
     const bool single = !(f & M2F_NOT_SINGLE), gray = !single && !(f & M2F_NOT_GRAY);
     if (single || (gray != (slot >= 17))) return;  // colour tiles run slots 0..16, gray tiles 17..20
     uint8_t *sc = scratch2 + sbase2[tile];
-    const uint8_t *in = sc + m2_off_stream(t.n, slot);
+    const uint8_t *in = sc + m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot);
     const uint32_t n = sgpr(stream_n[(uint64_t)tile * M2_SLOTS + slot]);
     const uint32_t Nnom = m2_nominal(slot);
     const int pb = slot >= 17 ? 15 : 14;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     uint8_t *sc = scratch2 + sbase2[tile];
     W1Prep *p = prep + (uint64_t)tile * M2_SLOTS + slot;
     live = live && p->kind == 1;
-    const uint8_t *in = sc + m2_off_stream(t->n, slot);  // 16-byte aligned
+    const uint8_t *in = sc + m2_off_stream(t->n, stream_n + (uint64_t)tile * M2_SLOTS, slot);  // 64-byte aligned
     const uint32_t n = live ? stream_n[(uint64_t)tile * M2_SLOTS + slot] : 0;
     const uint32_t pairs = n >> 1;
     // chunk c = pairs 8c .. 8c+7 (16 bytes); a lane walks its chunks from the top one down to 0, and all lanes of the wave reach

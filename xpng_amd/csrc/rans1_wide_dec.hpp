@@ -23,7 +23,7 @@ __device__ __constant__ const uint8_t W1D_BIG_SLOT[7] = {10, 12, 13, 14, 15, 16,
 __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restrict__ info, const TileDesc *__restrict__ tiles, TileSel sel,
                                                        const M2Blk *__restrict__ blk, const uint16_t *__restrict__ tabs,
                                                        uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
-                                                       WDec *__restrict__ wdec, uint8_t *__restrict__ dtab) {
+                                                       const uint32_t *__restrict__ stream_n, WDec *__restrict__ wdec, uint8_t *__restrict__ dtab) {
     __shared__ uint32_t fc[256];
     const uint32_t j = blockIdx.x / 18, slot = blockIdx.x % 18, lane = threadIdx.x & 63;
     WDec *wd = wdec + (uint64_t)j * M2_SLOTS + slot;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restri
     const uint32_t tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
     const M2Blk mb = blk[(uint64_t)tile * M2_SLOTS + slot];
-    const uint64_t out_off = sbase2[tile] + m2_off_stream(t.n, slot);
+    const uint64_t out_off = sbase2[tile] + m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, slot);
     uint8_t *out = scratch2 + out_off;
     const uint32_t type = sgpr(mb.type), n = sgpr(mb.n);
     const uint32_t Nnom = m2_nominal(slot);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
 
 inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t total, const M2DecTile *d_info2, const TileDesc *d_tiles,
                           TileSel sel, const M2Blk *d_blk2, const uint16_t *d_tabs2, uint8_t *d_scratch2, const uint64_t *d_sbase2,
-                          hipStream_t s, std::string &err) {
+                          const uint32_t *d_stream_n2, hipStream_t s, std::string &err) {
     const uint64_t need = (uint64_t)B * n_tiles * M2_SLOTS;
     if (ws.cap2 < need) {
         if (ws.d_wdec2) (void)hipFree(ws.d_wdec2);
@@ -312,7 +312,7 @@ inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t t
         ws.cap2 = need;
     }
     const uint32_t groups = (total + 31) / 32;
-    k_rans1_dec_prep<<<total * 18, 64, 0, s>>>(d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, ws.d_wdec2, ws.d_dtab2);
+    k_rans1_dec_prep<<<total * 18, 64, 0, s>>>(d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, d_stream_n2, ws.d_wdec2, ws.d_dtab2);
     // the two chain launches are independent: the big-alphabet slots run on the side stream beside the small ones
     if (!ws.side) {
         if (chain_stream_create(&ws.side) != hipSuccess ||

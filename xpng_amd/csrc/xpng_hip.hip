@@ -496,6 +496,7 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     k_m2_classify<<<total * 16, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, 16, c->d_flags2);
     if (launch_transform<3>(c, nimg, t0, t1, s)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes (allocates them on first use)
     XPNG_REQUIRE(c->d_planes);
+    k_m2_count<<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->d_stream_n2);  // stream lengths -> where every stream goes
     if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_streams<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     else k_m2_streams<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     const uint32_t gbpt = (max_n + 256 * M2_GRAY_REPS - 1) / (256 * M2_GRAY_REPS);
@@ -516,7 +517,7 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         k_rans1_finish<<<total * M2_SLOTS, 64, 0, s>>>(c->d_tiles, sel, c->d_scratch2, c->d_sbase2, c->d_stream_n2, c->d_blk2, c->d_w1prep, c->d_w1F);
     }
     k_m2_select<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, c->d_flags2, c->d_blk2, c->d_mt2, c->d_tile_sz);
-    k_m2_bits<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2);
+    k_m2_bits<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     k_tile_offsets<<<nimg, 256, 0, s>>>(c->d_tile_sz, cnt, c->d_off, c->d_totals);
     k_m2_gather<<<total, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_sums, c->d_mt2, c->d_blk2, c->d_scratch2, c->d_sbase2, c->d_off, c->d_out_ptrs);
     HIPCHK(hipGetLastError());
@@ -572,9 +573,9 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles, c->dec.arena);
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
-        XPNG_REQUIRE(c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2);
+        XPNG_REQUIRE(c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
         return decode_m2_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off, (uint32_t)t0,
-                                (uint32_t)t1, c->d_dec_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, s, g_err);
+                                (uint32_t)t1, c->d_dec_out_ptrs, c->d_info2, c->d_blk2, c->d_tabs2, c->d_scratch2, c->d_sbase2, c->d_stream_n2, s, g_err);
     }
     return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off,
                             (uint32_t)t0, (uint32_t)t1, c->d_dec_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr,
