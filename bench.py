@@ -375,7 +375,7 @@ def main():
                     help="contexts (each with its own HIP stream and buffers) that consecutive steps alternate between, so the "
                          "encode of step k+1 runs beside the decode of step k; 1 = strictly serial steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")
-    ap.add_argument("--batch", type=int, default=64,
+    ap.add_argument("--batch", type=int, default=128,
                     help="images per launch per rank: a step encodes+decodes `batch` rasters of the workload in one batched launch "
                          "sequence (the entropy stage is a serial chain per tile stream, so one image alone cannot fill 256 CUs)")
     ap.add_argument("--probe-run", action="store_true", help="tools only: load libxpng_hip_probes.so and accept timing-study switches; the line is marked probe_run and is not a benchmark")
@@ -409,7 +409,8 @@ def main():
         # memory and a down-clocked part, and its bandwidth-bound roofline pair reads 0.31-0.36 instead of the 0.55 of a clean run
         env.torch.cuda.empty_cache()
         for name, lvl in (("rgb_l1", 1), ("rgb_l2", 2)):
-            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 32)), "--pipeline", str(min(P, 4)),
+            # (level 2 holds 27 B/px of workspace against level 1's 12: 96 rasters per launch instead of 128 keep it at ~213 GB)
+            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 128 if lvl == 1 else 96)), "--pipeline", str(min(P, 4)),
                    "--steps", str(max(6, args.steps // 3)), "--warmup", "2", "--roofline-reps", str(max(10, args.roofline_reps // 2)), "--no-legs", "--no-config4"]
             if args.no_cpu:
                 cmd.append("--no-cpu")
@@ -434,12 +435,30 @@ def main():
         # Its >= 6x target at 8 GPUs is a THROUGHPUT figure (rasters per launch x pipeline slots): the latency of one raster is
         # one longest entropy chain per tile whatever N is.
         b4, p4 = (4 if world == 1 else max(2, 8 // world)), 2
-        r = run_leg(env, 16384, 16384, True, 1, b4, p4, max(4, args.steps // 8), 1, kind=args.kind)
-        r.pop("host_raster")
-        config4 = {"workload": "16384x16384 synthetic 'photo' RGBA8, level -1: ONE fixed raster geometry, 1369 tiles cut into contiguous ranges over the ranks",
-                   "scaling": "strong", "value": round(r["mpx_s"], 1), "unit": "Mpx/s", "ms_per_step": round(r["ms_per_step"], 3),
-                   "rasters_per_launch": r["B"], "pipeline_slots": r["P"], "tiles_per_rank": r["tiles_per_rank"],
-                   "compressed_bytes": r["compressed_bytes"], "verified": r["verified"], "hbm_in_use_gb": r["hbm_in_use_gb"]}
+        wl4 = "16384x16384 synthetic 'photo' RGBA8, level -1: ONE fixed raster geometry, 1369 tiles cut into contiguous ranges over the ranks"
+        if world == 1:
+            # N = 1: a CHILD process, like the RGB legs (measured in this process behind the 183 GB headline leg the same leg
+            # reads 26 instead of 29.5-30.6 Gpx/s: fragmented device memory)
+            env.torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--image", "16384", "--batch", str(b4), "--pipeline", str(p4), "--steps", str(max(6, args.steps // 4)),
+                   "--warmup", "2", "--roofline-reps", "2", "--no-legs", "--no-config4", "--no-cpu"]
+            if args.probe_run:
+                cmd.append("--probe-run")
+            try:
+                out_c = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+                c = json.loads([ln for ln in out_c.stdout.splitlines() if ln.startswith("{")][-1])
+                config4 = {"workload": wl4, "scaling": "strong", "value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"],
+                           "rasters_per_launch": c["config"]["batch"], "pipeline_slots": c["config"]["pipeline_slots"], "tiles_per_rank": c["config"]["tiles_per_rank"],
+                           "compressed_bytes": c["config"]["compressed_bytes"], "verified": c["verified"], "hbm_in_use_gb": c["config"]["hbm_in_use_gb"],
+                           "command": "python bench.py " + " ".join(cmd[2:])}
+            except Exception as ex:
+                config4 = {"workload": wl4, "error": f"{type(ex).__name__}: {ex}"}
+        else:
+            r = run_leg(env, 16384, 16384, True, 1, b4, p4, max(4, args.steps // 8), 1, kind=args.kind)
+            r.pop("host_raster")
+            config4 = {"workload": wl4, "scaling": "strong", "value": round(r["mpx_s"], 1), "unit": "Mpx/s", "ms_per_step": round(r["ms_per_step"], 3),
+                       "rasters_per_launch": r["B"], "pipeline_slots": r["P"], "tiles_per_rank": r["tiles_per_rank"],
+                       "compressed_bytes": r["compressed_bytes"], "verified": r["verified"], "hbm_in_use_gb": r["hbm_in_use_gb"]}
 
     if rank == 0:
         r = main_res
