@@ -51,22 +51,30 @@ struct BitW {
 // per workgroup) and communicate through LDS arrays owned by the kernel.
 
 // symbol histogram of in[0..n) into hist[256]
+// (the reference counts F[] while routing; same numbers).  16 symbols per lane per load, counted by LDS atomics into HSUB
+// sub-histograms (lane % HSUB).  The streams are skewed - most alpha symbols of a tile are one value, a context stream has nine -
+// and an LDS atomic serialises the lanes of an instruction that hit the same BANK, whether or not they hit the same word: with
+// the sub-histograms 256 words apart (rounds 1-3: four of them) every lane counting the dominant symbol sat in one bank, 64
+// deep.  Here consecutive sub-histograms are 258 words apart, i.e. two banks, so the 64 lanes spread over 16 banks, 4 deep.
+constexpr uint32_t HSUB = 16, HSTRIDE = 258;
 __device__ inline void rans_histogram(const uint8_t *__restrict__ in, uint32_t n, uint32_t *hist) {
     const uint32_t lane = threadIdx.x & 63;
-    // (the reference counts F[] while routing; same numbers).  16 symbols per lane per load; four
-    // sub-histograms (lane & 3) cut the same-address LDS atomic serialisation of skewed streams.
-    __shared__ uint32_t hsub[4][256];
-    for (uint32_t i = lane; i < 1024; i += 64) (&hsub[0][0])[i] = 0;
+    __shared__ uint32_t hsub[HSUB * HSTRIDE];
+    for (uint32_t i = lane; i < HSUB * HSTRIDE; i += 64) hsub[i] = 0;
     __syncthreads();
     {
-        uint32_t *hs = hsub[lane & 3];
+        uint32_t *hs = hsub + (lane % HSUB) * HSTRIDE;
         const uint32_t head = (uint32_t)((16 - ((uintptr_t)in & 15)) & 15);
         const uint32_t nh = head < n ? head : n;
         if (lane < nh) atomicAdd(&hs[in[lane]], 1u);
         const uint32_t vecs = (n - nh) >> 4;
         const uint4 *v = reinterpret_cast<const uint4 *>(in + nh);
+        // (the next 16 bytes are requested before this iteration's sixteen atomics, from a clamped index: no branch around the load)
+        uint4 nx = make_uint4(0, 0, 0, 0);
+        if (vecs) nx = v[lane < vecs ? lane : vecs - 1];
         for (uint32_t i = lane; i < vecs; i += 64) {
-            const uint4 q = v[i];
+            const uint4 q = nx;
+            nx = v[i + 64 < vecs ? i + 64 : vecs - 1];
             const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -79,7 +87,12 @@ __device__ inline void rans_histogram(const uint8_t *__restrict__ in, uint32_t n
         for (uint32_t i = nh + (vecs << 4) + lane; i < n; i += 64) atomicAdd(&hs[in[i]], 1u);
     }
     __syncthreads();
-    for (uint32_t i = lane; i < 256; i += 64) hist[i] = hsub[0][i] + hsub[1][i] + hsub[2][i] + hsub[3][i];
+    for (uint32_t i = lane; i < 256; i += 64) {
+        uint32_t t = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < HSUB; k++) t += hsub[k * HSTRIDE + i];
+        hist[i] = t;
+    }
     __syncthreads();
 }
 
