@@ -14,9 +14,10 @@ print('legs',{k:(v.get('value'),v.get('hbm_in_use_gb')) for k,v in d.get('legs',
 print('config4',d.get('config4'))
 print('cpu',d.get('cpu_baseline'))"
 bash tools/prof_stats.sh final_prof --no-legs --no-config4 || exit 1
-python3 tools/profile_digest.py gpurun_out/final_prof/p_kernel_trace.csv gpurun_out/final_prof.log > gpurun_out/final_prof_digest.json && echo digest ok
-bash tools/prof_pmc_mem.sh 64 > gpurun_out/final_pmc_step_mem.json 2> gpurun_out/final_pmc_step_mem.err || exit 1
+grep '^{' gpurun_out/final_prof.log | tail -1 > gpurun_out/final_prof_line.json
+python3 tools/profile_digest.py gpurun_out/final_prof/p_kernel_trace.csv gpurun_out/final_prof_line.json > gpurun_out/final_prof_digest.json && echo digest ok
+bash tools/prof_pmc_mem.sh 64 2> gpurun_out/final_pmc_step_mem.err | sed -n '/^{/,$p' > gpurun_out/final_pmc_step_mem.json || exit 1
 python3 -c "
 import json
-d=json.load(open('gpurun_out/final_pmc_step_mem.json')) if open('gpurun_out/final_pmc_step_mem.json').read().strip().startswith('{') else None
+d=json.load(open('gpurun_out/final_pmc_step_mem.json'))
 print('step traffic B/px', d and d.get('bytes_per_px'))"
