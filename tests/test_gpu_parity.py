@@ -518,9 +518,10 @@ def test_mode2_large_batch_takes_the_wide_path_and_matches(gpu, po):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k_syms", [3, 30, 47, 49, 64, 200])
 def test_alpha_alphabet_sizes_on_the_wide_path(gpu, po, monkeypatch, k_syms):
-    """The wide alpha encode chain keeps a compact table (symbol -> rank map + used entries) in LDS when at most 48 of the
-    256 alpha symbols occur and reads the full table from HBM otherwise; the wide alpha decode chain uses 16-bit cumulative
-    tables.  Alphabets on both sides of that boundary, bytes against the oracle, then the round trip."""
+    """The wide alpha encode chain gathers its table entries from the stream's 4 KB table in global memory one block ahead (a
+    compact LDS form for alphabets of at most 48 symbols existed through round 3); the wide alpha decode chain uses 16-bit
+    cumulative tables with a coarse table indexed by cold rank.  Alphabets from 3 to 200 symbols, bytes against the oracle, then
+    the round trip."""
     monkeypatch.setenv("XPNG_WIDE_RANS", "1")
     from xpng_amd.synth import synth_raster
     rng = np.random.default_rng(k_syms)
