@@ -190,6 +190,15 @@ __device__ __forceinline__ uint32_t load_px(const uint8_t *p) {
 
 constexpr uint64_t RANS_L = 1ull << 31;  // reference RANS64_L, libxpng.c:153
 
+// Word staging of the wide ENCODE chains (k_rans2_chain2, k_rans1_chain): every stream of a wave owns WB_STRIDE words of LDS -
+// 16 staged words and a dump word for the lanes that emit nothing in a step, which is most lanes in most steps.  The stride
+// and the dump word's place are chosen by LDS BANK: with 32 words per stream (rounds 1-3) all 64 lanes of a step's store hit
+// banks 16 and 17 - a 32-deep serialised store per step and wave, 16-26 conflict cycles per LDS instruction in the counters,
+// and every LDS access of the compute unit queues behind it.  With 36 words per stream (a multiple of 16 bytes: the staged
+// words leave as 16-byte reads) and the dump word at 16 + 2 (stream / 8) + parity the 64 lanes fall on 32 banks, two deep.
+constexpr uint32_t WB_STRIDE = 36;
+__device__ __forceinline__ uint32_t wb_dump(uint32_t stream, uint32_t par) { return 16u + 2u * (stream >> 3) + par; }
+
 // swap values between lanes 2k and 2k+1 (DPP quad_perm [1,0,3,2]); VALU only, no LDS round trip
 __device__ __forceinline__ uint32_t swap_pair(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);

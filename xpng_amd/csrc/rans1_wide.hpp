@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_rans1_prep(const TileDesc *__restrict__ 
 
 // BIG: slots 15..20 (tables of 2-4 KB), 16 tiles per wave (32 lanes); else slots 0..14 (tables <= 1 KB), 32 tiles per wave.
 template <bool BIG> constexpr uint32_t rans1_chain_ltab_bytes() { return (BIG ? 16u : 32u) * ((BIG ? 4096u : 1024u) + 16u); }
-template <bool BIG> constexpr size_t rans1_chain_lds_bytes() { return rans1_chain_ltab_bytes<BIG>() + (BIG ? 16u : 32u) * 32u * 4u; }  // dynamic LDS (common.hpp: why dynamic)
+template <bool BIG> constexpr size_t rans1_chain_lds_bytes() { return rans1_chain_ltab_bytes<BIG>() + (BIG ? 16u : 32u) * WB_STRIDE * 4u; }  // dynamic LDS (common.hpp: why dynamic)
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                     uint8_t *__restrict__ scratch2, const uint64_t *__restrict__ sbase2,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     static_assert(TPW * TSTRIDE == rans1_chain_ltab_bytes<BIG>() && (TPW * TSTRIDE) % 16 == 0, "LDS layout");
     extern __shared__ __align__(16) uint8_t rans1_chain_lds[];
     uint8_t *const ltab = rans1_chain_lds;                                                  // [TPW * TSTRIDE]
-    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(rans1_chain_lds + TPW * TSTRIDE);   // [TPW * 32] per stream: 16 staged words + 16 nobody reads
+    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(rans1_chain_lds + TPW * TSTRIDE);   // [TPW * WB_STRIDE] per stream: 16 staged words + dump words nobody reads (common.hpp)
     __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t slot = (BIG ? 15u : 0u) + blockIdx.x % NSLOT, grp = blockIdx.x / NSLOT;
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
     const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
     uint32_t *out = reinterpret_cast<uint32_t *>(sc + m2_off_blk(t->n, stream_n + (uint64_t)tile * M2_SLOTS, slot));
     uint32_t *w = out + 4;
-    uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
+    uint32_t *wb = wbuf + (k < TPW ? k : 0) * WB_STRIDE;
+    const uint32_t dumpw = wb_dump(k < TPW ? k : 0, par);
     const uint32_t cmpl_base = 1u << pb;
     const int thr_shift = 31 - pb;
     uint64_t s = RANS_L;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64) void k_rans1_chain(const TileDesc *__restrict__
                 const uint32_t freq = e.freq_shift & 0xFFFF;
                 const uint32_t emit = (act && (uint32_t)(s >> 32) >= (freq << thr_shift)) ? 1u : 0u;
                 const uint32_t other = swap_pair(emit);
-                wb[emit ? cb + (par ? 0u : other) : 16u + par] = (uint32_t)s;  // state1's word first (libxpng.c:229-236)
+                wb[emit ? cb + (par ? 0u : other) : dumpw] = (uint32_t)s;  // state1's word first (libxpng.c:229-236)
                 if (emit) s >>= 32;
                 cb += emit + other;
                 if (act) put(e);

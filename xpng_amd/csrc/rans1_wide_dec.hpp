@@ -128,7 +128,7 @@ template <bool BIG> struct Dec1ChainLds {  // dynamic LDS layout of one launch (
     typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
     static constexpr uint32_t STREAMS = 32, TSTRIDE = L::TAB + 4, RSTRIDE = 4 * L::RING + 4;
     static constexpr uint32_t OFF_RING = (STREAMS * TSTRIDE + 15u) & ~15u, OFF_OBUF = (OFF_RING + STREAMS * RSTRIDE + 31u) & ~31u;
-    static constexpr size_t BYTES = OFF_OBUF + STREAMS * 32;
+    static constexpr size_t BYTES = OFF_OBUF + STREAMS * OB_STRIDE + 12;
 };
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restrict__ info, uint32_t total, const WDec *__restrict__ wdec,
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     extern __shared__ __align__(32) uint8_t dec1_chain_lds[];
     uint8_t *const ltab = dec1_chain_lds;                 // [STREAMS * TSTRIDE]
     uint8_t *const ring = dec1_chain_lds + LD::OFF_RING;  // [STREAMS * RSTRIDE]
-    uint8_t *const obuf = dec1_chain_lds + LD::OFF_OBUF;  // [STREAMS * 32]
+    uint8_t *const obuf = dec1_chain_lds + LD::OFF_OBUF;  // [STREAMS * OB_STRIDE]
     __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t slot = BIG ? W1D_BIG_SLOT[blockIdx.x % NSLOT] : W1D_SMALL_SLOT[blockIdx.x % NSLOT], grp = blockIdx.x / NSLOT;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
     const uint32_t ident = 1u << pb;
     const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + L::CO_OFF;
     const uint32_t a_ring = (uint32_t)(uintptr_t)(lds8 *)ring + k * RSTRIDE;  // word slot i at a_ring + 4 i, the mirror of slot 0 at slot RING
-    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + k * 32;
+    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + k * OB_STRIDE;
     auto ring_w = [&](uint32_t idx) __attribute__((always_inline)) -> lds32 * { return (lds32 *)(uintptr_t)(a_ring + 4 * (idx & (RING - 1))); };
     // ---- initial ring contents: the first RING words; the states sit right below the words
     uint32_t rw = 0;                          // next word to read is words[rw]
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restr
             }
         }
         *(lds32 *)(uintptr_t)(a_ring + 4 * RING) = *ring_w(0);
-        if (tb < pairs + (n & 1u) && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * tb) = *(const lds128 *)(uintptr_t)a_ob;
+        if (tb < pairs + (n & 1u) && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * tb) = *(const lds128_al4 *)(uintptr_t)a_ob;
         hi = hif;
         {   // request the words above: keep the ring at most RING ahead of the cursor, at most 2 PER words per boundary.
             // The loads are issued on EVERY boundary, from word 0 when there is nothing to fetch (fhi = 0 then keeps the landing

@@ -82,7 +82,10 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
 // gfx9, where stores count on vmcnt).
 typedef uint32_t u32x4_enc __attribute__((ext_vector_type(4)));
 template <bool BIG> constexpr uint32_t chain2_ltab_bytes() { return BIG ? 0u : 32u * (144u + 16u); }
-template <bool BIG> constexpr size_t chain2_lds_bytes() { return chain2_ltab_bytes<BIG>() + 32u * 32u * 4u; }  // dynamic LDS of one launch (common.hpp: why dynamic)
+// (Round 3 tried the context class with its symbols requested THREE blocks ahead through an LDS ring filled by LDS-DMA loads -
+//  global_load_lds_dwordx4, the mechanism of tools/ubench/ldsdma.hip - bit-exact, 60 GPU tests green: 6.5 -> 7.5 ms alone, 11.2 ms
+//  median in the pipeline before and after.  This chain does not wait for its symbols there; removed.  DESIGN.md 6.2b.)
+template <bool BIG> constexpr size_t chain2_lds_bytes() { return chain2_ltab_bytes<BIG>() + 32u * WB_STRIDE * 4u; }  // dynamic LDS of one launch (common.hpp: why dynamic)
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     static_assert((BIG || TPW * TSTRIDE == chain2_ltab_bytes<BIG>()) && (TPW * TSTRIDE) % 16 == 0, "LDS layout");
     extern __shared__ __align__(16) uint8_t chain2_lds[];
     uint8_t *const ltab = chain2_lds;                                                               // [TPW * TSTRIDE] (context class only)
-    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(chain2_lds + chain2_ltab_bytes<BIG>());     // [TPW * 32] per stream: 16 staged words + 16 nobody reads
+    uint32_t *const wbuf = reinterpret_cast<uint32_t *>(chain2_lds + chain2_ltab_bytes<BIG>());     // [TPW * WB_STRIDE] per stream: 16 staged words + dump words nobody reads (common.hpp)
     __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     T = sgpr((T + 7) & ~7u); Tmin = sgpr(Tmin);
     const EncSym *tab = reinterpret_cast<const EncSym *>(ltab + (k < TPW ? k : 0) * TSTRIDE);
     uint32_t *w = reinterpret_cast<uint32_t *>(sc + off_blk(t->n, ctx_n + (uint64_t)tile * 9, (int)c)) + 3;
-    uint32_t *wb = wbuf + (k < TPW ? k : 0) * 32;
+    uint32_t *wb = wbuf + (k < TPW ? k : 0) * WB_STRIDE;
+    const uint32_t dumpw = wb_dump(k < TPW ? k : 0, par);
     // symbols of block b (pair symbols 16b .. 16b+15) = bytes [16b + SH, 16b + SH + 16) of `in`
     uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;  // in flight: the block after the current one
     // (unconditional, on a clamped block index: a branch around the loads makes the compiler keep the loaded values in
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
                 // of a wave spill in about a third of the steps (a state spills once in ~160), so most steps are the arithmetic only
                 if (!BIG || __ballot(emit)) {
                     const uint32_t other = swap_pair(emit);
-                    wb[emit ? cb + (par ? other : 0u) : 16u + par] = (uint32_t)s;  // state0's word first (libxpng.c:370-373)
+                    wb[emit ? cb + (par ? other : 0u) : dumpw] = (uint32_t)s;  // state0's word first (libxpng.c:370-373)
                     if (emit) s >>= 32;
                     cb += emit + other;
                 }

@@ -206,6 +206,14 @@ typedef __attribute__((address_space(3))) uint32_t lds32;
 typedef __attribute__((address_space(3))) uint16_t lds16;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds128;
+// Symbol staging of the wide DECODE chains: every stream of a wave owns OB_STRIDE bytes of LDS - the 16 symbol bytes of a block and
+// a dump byte for inactive steps.  36 bytes, not 32: a step stores one byte per lane at the same position of every stream, and
+// with 32 bytes per stream eight streams share each bank (an 8-deep serialised store per step; 4 conflict cycles per LDS
+// instruction in the counters), with 9 words per stream the 32 streams fall on 32 banks.  The block's 16 bytes leave by a
+// 4-byte aligned 16-byte read.
+constexpr uint32_t OB_STRIDE = 36;
+typedef u32x4_t u32x4_al4 __attribute__((aligned(4)));
+typedef __attribute__((address_space(3))) u32x4_al4 lds128_al4;
 
 // Per decode step and lane (fast path, every lane active): slot -> coarse byte -> (F | cum << 16) are two dependent LDS reads; the
 // state update is one 64x32 multiply-add built from v_mad_u64_u32 + v_mad_u32_u24 (the high half of s >> pb is < 2^21,
@@ -219,7 +227,7 @@ template <bool BIG, int STREAMS> struct DecChainLds {  // dynamic LDS layout of 
     typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
     static constexpr uint32_t LTAB = BIG ? L::TAB : L::CO_OFF, TSTRIDE = LTAB + 4, RSTRIDE = 4 * L::RING + 4;
     static constexpr uint32_t OFF_RING = (STREAMS * TSTRIDE + 15u) & ~15u, OFF_OBUF = (OFF_RING + STREAMS * RSTRIDE + 31u) & ~31u;
-    static constexpr size_t BYTES = OFF_OBUF + (STREAMS + 1) * 32;
+    static constexpr size_t BYTES = OFF_OBUF + (STREAMS + 1) * OB_STRIDE + 12;
 };
 template <bool BIG, int STREAMS, bool HOT>
 __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restrict__ info, uint32_t total, uint32_t c_first,
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     extern __shared__ __align__(32) uint8_t dec_chain_lds[];
     uint8_t *const ltab = dec_chain_lds;                 // [WD_STREAMS * TSTRIDE]
     uint8_t *const ring = dec_chain_lds + LD::OFF_RING;  // [WD_STREAMS * RSTRIDE]
-    uint8_t *const obuf = dec_chain_lds + LD::OFF_OBUF;  // [(WD_STREAMS + 1) * 32] per stream: 16 symbol bytes of the block + 16 bytes nobody reads; the last slot belongs to the lanes without a stream (STREAMS < 32)
+    uint8_t *const obuf = dec_chain_lds + LD::OFF_OBUF;  // [(WD_STREAMS + 1) * OB_STRIDE] per stream: 16 symbol bytes of the block + a dump byte nobody reads; the last slot belongs to the lanes without a stream (STREAMS < 32)
     const uint32_t lane = threadIdx.x & 63, kraw = lane >> 1, k = kraw < WD_STREAMS ? kraw : 0, par = lane & 1;  // (idle lanes alias stream 0's LDS harmlessly)
     const uint32_t c = c_first + blockIdx.x % c_count, grp = blockIdx.x / c_count;
     const uint32_t j = grp * WD_STREAMS + kraw;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
     // LDS byte addresses
     const uint32_t a_fc = (uint32_t)(uintptr_t)(lds8 *)ltab + k * TSTRIDE, a_co = a_fc + L::CO_OFF;
     const uint32_t a_ring = (uint32_t)(uintptr_t)(lds8 *)ring + k * RSTRIDE + 4;  // word slot i at a_ring + 4 i, the mirror at a_ring - 4
-    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + (kraw < WD_STREAMS ? kraw : WD_STREAMS) * 32;
+    const uint32_t a_ob = (uint32_t)(uintptr_t)(lds8 *)obuf + (kraw < WD_STREAMS ? kraw : WD_STREAMS) * OB_STRIDE;
     auto ring_w = [&](uint32_t idx) __attribute__((always_inline)) -> lds32 * { return (lds32 *)(uintptr_t)(a_ring + 4 * (idx & (WD_RING - 1))); };
     // ---- initial ring contents: the top 64 words; the states sit right above the words
     uint32_t rw = nw;                               // next word to pop is words[rw - 1]
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
             }
         }
         *(lds32 *)(uintptr_t)(a_ring - 4) = *ring_w(WD_RING - 1);
-        if (jb < npairs && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * jb) = *(const lds128 *)(uintptr_t)a_ob;
+        if (jb < npairs && par == 0) *reinterpret_cast<u32x4_t *>(out + 2ull * jb) = *(const lds128_al4 *)(uintptr_t)a_ob;
         lo = lof;
         {
             int32_t want = (int32_t)lo - (int32_t)(2 * PER);
