@@ -546,7 +546,9 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
 // with hist = histogram of the nl plane over coded pixels.  One 256-thread workgroup per tile reads the plane once (16 pixels
 // per thread and step; nine 7-bit fields of a 64-bit accumulator, spilled into nine counters every 7 steps).
 // core: histogram of the tile's nl plane over coded pixels -> s_hist[9] (LDS), and s_last = (index of the last coded pixel + 1) << 4 |
-// its nl (0: the tile codes no pixel).  256-thread workgroup; both LDS objects are valid after the closing barrier.
+// its nl (0: the tile codes no pixel).  THREADS-thread workgroup (256 for batches, 1024 for a few tiles: the pass sits on a lone
+// image's critical path); both LDS objects are valid after the closing barrier.
+template <int THREADS>
 __device__ __forceinline__ void tile_nl_histogram(const TileDesc &t, const uint8_t *__restrict__ planes, uint32_t *s_hist, uint32_t *s_last) {
     const uint32_t tid = threadIdx.x;
     const uint4 *pnl = reinterpret_cast<const uint4 *>(planes + t.pbase);  // (plane bases are multiples of 256; >= 192 bytes of slack behind a tile)
@@ -561,7 +563,7 @@ __device__ __forceinline__ void tile_nl_histogram(const TileDesc &t, const uint8
         for (int c = 0; c < 9; c++) cnt[c] += (uint32_t)(acc >> (7 * c)) & 127u;
         acc = 0; pend = 0;
     };
-    for (uint32_t i0 = 16 * tid; i0 < t.n; i0 += 16 * 256) {
+    for (uint32_t i0 = 16 * tid; i0 < t.n; i0 += 16 * THREADS) {
         const uint4 v = pnl[i0 >> 4];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -590,13 +592,14 @@ __device__ __forceinline__ void tile_nl_histogram(const TileDesc &t, const uint8
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_m1_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint8_t *__restrict__ planes,
-                                                  uint32_t *__restrict__ ctx_n) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_m1_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint8_t *__restrict__ planes,
+                                                      uint32_t *__restrict__ ctx_n) {
     const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
     const TileDesc t = tiles[tile];
     __shared__ uint32_t s_hist[9];
     __shared__ uint32_t s_last;
-    tile_nl_histogram(t, planes, s_hist, &s_last);
+    tile_nl_histogram<THREADS>(t, planes, s_hist, &s_last);
     if (tid < 9) {
         const uint32_t l = s_last;
         uint32_t len = s_hist[tid];

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_m2_classify(const uint8_t *const *__res
 // stream lengths of every tile, before anything is routed (the layout above needs them): a colour tile's nine context streams as
 // in k_m1_count, its class stream v holds one symbol (v = 1, 2) or three (v >= 3) per coded pixel with nl = v; a gray tile's four
 // candidate streams hold n - 1 symbols each; everything else 0.   grid = tiles, block = 256.
-__global__ __launch_bounds__(256) void k_m2_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_m2_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
                                                   const uint8_t *__restrict__ planes, uint32_t *__restrict__ stream_n) {
     const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
     const TileDesc t = tiles[tile];
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_m2_count(const TileDesc *__restrict__ t
     }
     __shared__ uint32_t s_hist[9];
     __shared__ uint32_t s_last;
-    tile_nl_histogram(t, planes, s_hist, &s_last);
+    tile_nl_histogram<THREADS>(t, planes, s_hist, &s_last);
     if (tid < 9) {
         const uint32_t l = s_last;
         uint32_t len = s_hist[tid];

@@ -444,7 +444,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
     }
     // stream lengths (histogram of the nl plane) -> places of the nine context streams -> routing
-    if (!dbg_skip("count")) k_m1_count<<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_planes, c->d_ctx_n);
+    if (dbg_skip("count")) {} else if (small_wg) k_m1_count<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_planes, c->d_ctx_n);
+    else k_m1_count<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_planes, c->d_ctx_n);
     if (dbg_skip("streams")) {} else if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     if (narrow) {
@@ -496,7 +497,8 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     k_m2_classify<<<total * 16, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, 16, c->d_flags2);
     if (launch_transform<3>(c, nimg, t0, t1, s)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes (allocates them on first use)
     XPNG_REQUIRE(c->d_planes);
-    k_m2_count<<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->d_stream_n2);  // stream lengths -> where every stream goes
+    if ((uint64_t)total * M2_STREAMS > 2048) k_m2_count<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->d_stream_n2);  // stream lengths -> where every stream goes
+    else k_m2_count<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->d_stream_n2);
     if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_streams<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     else k_m2_streams<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     const uint32_t gbpt = (max_n + 256 * M2_GRAY_REPS - 1) / (256 * M2_GRAY_REPS);
