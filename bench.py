@@ -150,7 +150,7 @@ class Env:
         self.torch.cuda.synchronize()
 
 
-def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline_reps=0, single=False):
+def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline_reps=0, single=False, stagger_ms=0.0):
     """One workload through the pipelined hot path: verify, (roofline pair), W warmup + K timed steps, re-verify.
     Returns a dict of measurements (rank 0 fills the reference checks)."""
     import xpng_amd
@@ -310,8 +310,10 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
         step()
     env.barrier()
     t_start = time.perf_counter()
-    for _ in range(steps):
+    for si in range(steps):
         step()
+        if stagger_ms > 0 and si < len(slots) - 1:
+            time.sleep(stagger_ms * 1e-3)  # (experiment, inside the timed region: the slots start their cycles this far apart instead of together)
     env.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -378,6 +380,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128,
                     help="images per launch per rank: a step encodes+decodes `batch` rasters of the workload in one batched launch "
                          "sequence (the entropy stage is a serial chain per tile stream, so one image alone cannot fill 256 CUs)")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="experiment: host sleep between the first steps of the pipeline slots (warm-up), so that their cycles start apart; 0 = off")
     ap.add_argument("--probe-run", action="store_true", help="tools only: load libxpng_hip_probes.so and accept timing-study switches; the line is marked probe_run and is not a benchmark")
     args = ap.parse_args()
     env_seen = env_report(args.probe_run)
@@ -397,7 +400,7 @@ def main():
     B, P = max(1, args.batch), max(1, args.pipeline)
 
     main_res = run_leg(env, W, H, alpha, args.level, B, P, args.steps, args.warmup, kind=args.kind,
-                       roofline_reps=args.roofline_reps, single=True)
+                       roofline_reps=args.roofline_reps, single=True, stagger_ms=args.stagger_ms)
     host_raster = main_res.pop("host_raster")
     cpu = cpu_baseline(host_raster, args.level) if (world == 1 and rank == 0 and not args.no_cpu) else None
 
