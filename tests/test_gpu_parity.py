@@ -793,10 +793,14 @@ def test_context_stream_places_follow_their_lengths(gpu, po, monkeypatch, force_
     if force_wide:
         monkeypatch.setenv("XPNG_WIDE_RANS", "1")
     cases = [("photo", 700, 500, True), ("photo", 700, 500, False), ("noise", 300, 200, True), ("flat", 500, 460, False),
-             ("photo", 1200, 3, False), ("photo", 5, 900, True)]
+             ("photo", 1200, 3, False), ("photo", 5, 900, True), ("photo", 900, 460, "clear")]
     for kind, w, h, alpha in cases:
+        clear = alpha == "clear"  # RGBA whose first tile codes NO pixel at all (every stream length 0) beside an ordinary one
+        alpha = bool(alpha)
         raster = synth_raster(kind, w, h, alpha, seed=11)
-        if alpha:
+        if clear:
+            raster[:, :456, 3] = 0                     # (tile 0 of a 900 x 460 raster is 456 x 460)
+        elif alpha:
             raster[h // 3: h // 3 + 7, :, 3] = 0          # runs of invisible pixels, also at the end of a row
             raster[-1, -max(1, w // 4):, 3] = 0           # the tile's LAST pixels are not coded: "last coded pixel" is further up
         hh, ww, ch = raster.shape
