@@ -868,6 +868,11 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     const uint32_t total = live ? d->ctx_start[9] : 0;
     const uintptr_t base = (uintptr_t)(ctxsym + t->pbase);
     uint8_t *out = nlseq + t->pbase;
+    // where a lane without (more) symbols stores: behind the nl sequence of the tile its `out` points at (the planes carry >= 192
+    // bytes of slack behind a tile; a lane without a tile points at its placeholder tile, whose sequence another lane may be writing)
+    const DecTile *dh = info + (live ? j : 0);  // the tile `out` points at
+    const uint32_t seq_here = (dh->type != 0 && dh->type != TILE_BAD) ? dh->ctx_start[9] : 0u;
+    const uint32_t dump = (seq_here + 15u) & ~15u;
     uint32_t qoff[9], have[9];
     u32x4_t fl[9][SVC];  // in flight per queue: chunks have .. have + SVC - 1
     typedef const __attribute__((address_space(1))) u32x4_t *gp128;
@@ -917,7 +922,10 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
             o[u >> 2] |= sym << (8 * (u & 3));
             cur = kb + (uint32_t)u + 1 >= total ? 9u : (sym < 9u ? sym : 9u);  // (symbols > 8 only in corrupt streams)
         }
-        if (kb < total) *reinterpret_cast<uint4 *>(out + kb) = make_uint4(o[0], o[1], o[2], o[3]);
+        // (an UNCONDITIONAL store: a lane past the end of its sequence writes its 16 bytes into the slack behind it.  Loads and stores
+        //  retire in order on gfx9; with a store that may or may not have been issued the wait in front of a landing has to assume it was
+        //  not, and then retires one load too many - one that is only a block old.)
+        *reinterpret_cast<uint4 *>(out + (kb < total ? kb : dump)) = make_uint4(o[0], o[1], o[2], o[3]);
     };
     // Service of the queues of one phase, every SVC-th block boundary (so a request has 16 * SVC steps, not 16, to come back:
     // 64 lanes x 9 queues are 576 different cache lines per round).  Up to SVC
