@@ -1660,7 +1660,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                 return bad("stream/event creation failed");
         }
         if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
-        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES + pad_ch, ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
