@@ -8,7 +8,7 @@
 //   k_rans1_decode   one wave per (tile, stream): forwards over the symbols, state0 refills before state1; same hot-symbol
 //                    cache / LDS tables / scalar word cursor as the v2 decoder
 //   ctx_walk         the nl context chain (shared with mode 1)
-//   k_m2_dec_resid   class-stream routing back to pixels (rank by nl via ballots), zig-zag / green add-back
+//   k_m2_dec_resid   class-stream routing back to pixels (rank by nl: packed prefix sums, four pixels per lane), zig-zag / green add-back
 //   k_m2_dec_recon   fill / raw copy / anti-diagonal wavefront (shared with mode 1); gray tiles use predictor m
 #pragma once
 #include "common.hpp"
@@ -324,52 +324,91 @@ __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__res
         }
         return;
     }
-    const uint8_t *nls = nlseq + t.pbase;
+    // colour: a lane owns FOUR consecutive pixels (their nl symbols are four consecutive bytes of the nl sequence: every pixel but the
+    // first is coded); the position of a pixel's symbol(s) in its class stream is a prefix sum of eight counters packed three 10-bit
+    // fields to a word: three DPP scans per 4 x THREADS pixels (rounds 1-3: one pixel per lane, eight ballots per THREADS pixels);
+    // the four residual words leave as one 16-byte store.  Two barriers per iteration.
+    const uint32_t *nls4 = reinterpret_cast<const uint32_t *>(nlseq + t.pbase);  // (plane bases are multiples of 256)
     const int useG = d.m & 1;
-    __shared__ uint32_t s_wave[THREADS / 64][9], s_run[9], s_off[9];
+    constexpr int WAVES = THREADS / 64, PX = THREADS * 4;
+    __shared__ uint32_t s_wave[WAVES][9], s_run[9], s_off[9];
+    __shared__ volatile uint32_t s_base[WAVES][16];
     if (tid < 9) s_run[tid] = 0;
     if (tid >= 1 && tid < 9) s_off[tid] = (uint32_t)m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, 8 + tid);  // class stream of nl = tid
     __syncthreads();
-    const uint64_t lt = lanemask_lt();
-    for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
-        const uint32_t i = i0 + tid;
-        const bool coded = i < t.n && i > 0;
-        const uint32_t nl = coded ? nls[i - 1] : 0;
-        uint32_t rank = 0, cnt = 0;
-#pragma unroll
-        for (uint32_t c = 1; c < 9; c++) {
-            const uint64_t m = __ballot(coded && nl == c);
-            if (nl == c) rank = (uint32_t)__popcll(m & lt);
-            if (lane == c) cnt = (uint32_t)__popcll(m);
-        }
-        if (lane >= 1 && lane < 9) s_wave[wv][lane] = cnt;
-        __syncthreads();
+    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);  // field of counter `lane` in the packed words
+    uint32_t py = (4 * tid) / t.w, px = 4 * tid - py * t.w;   // (x, y) of the lane's first pixel, advanced by PX pixels per iteration
+    const uint32_t dy = PX / t.w, dx = PX - dy * t.w;
+    for (uint32_t i0 = 0; i0 < t.n; i0 += PX) {
+        const uint32_t i = i0 + 4 * tid;
+        // nl of pixels i .. i+3 = bytes i-1 .. i+2 of the nl sequence (pixel 0 has none)
+        uint32_t u = 0;
         if (i < t.n) {
-            uint32_t word = 0;
-            if (coded) {
-                int dr = 0, dg = 0, db = 0;
-                if (nl) {
-                    uint32_t base = s_run[nl];
-                    for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave[w2][nl];
-                    const uint8_t *st = sc + s_off[nl];
-                    const uint32_t k = base + rank;
-                    uint32_t zr, zg, zb;
-                    if (nl == 1) { const uint32_t v = st[k]; zr = v >> 2; zg = (v >> 1) & 1; zb = v & 1; }
-                    else if (nl == 2) { const uint32_t v = st[k]; zr = v >> 4; zg = (v >> 2) & 3; zb = v & 3; }
-                    else { zr = st[3 * k]; zg = st[3 * k + 1]; zb = st[3 * k + 2]; }
-                    dr = zz_dec((int)zr); dg = zz_dec((int)zg); db = zz_dec((int)zb);
+            const uint32_t hi = nls4[i >> 2], lo = i ? nls4[(i >> 2) - 1] : 0u;
+            u = __builtin_amdgcn_alignbyte(hi, lo, 3);
+        }
+        uint32_t nl[4], csh[4], cinc[4][3], c0 = 0, c1 = 0, c2 = 0;
+        bool coded[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            coded[k] = i + k < t.n && i + k > 0;
+            nl[k] = coded[k] ? min((u >> (8 * k)) & 255u, 8u) : 0u;
+            const uint32_t v = nl[k], q = (v * 11u) >> 5;
+            csh[k] = 10u * (v - 3u * q);
+            const uint32_t one = v ? 1u << csh[k] : 0u;
+            cinc[k][0] = q == 0 ? one : 0u; cinc[k][1] = q == 1 ? one : 0u; cinc[k][2] = q == 2 ? one : 0u;
+            c0 += cinc[k][0]; c1 += cinc[k][1]; c2 += cinc[k][2];
+        }
+        const uint32_t y0 = wave_scan_incl(c0), y1 = wave_scan_incl(c1), y2 = wave_scan_incl(c2);
+        {
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)y0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)y1, 63),
+                           t2 = (uint32_t)__builtin_amdgcn_readlane((int)y2, 63);
+            const uint32_t word = myq == 0 ? t0 : (myq == 1 ? t1 : t2);
+            if (lane < 9) s_wave[wv][lane] = (word >> mysh) & 1023u;
+        }
+        __syncthreads();  // (A) per-wave class counts visible
+        if (lane < 9) {
+            uint32_t bk = s_run[lane];
+            for (uint32_t w = 0; w < wv; w++) bk += s_wave[w][lane];
+            s_base[wv][lane] = bk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (i < t.n) {
+            uint32_t f0 = y0 - c0, f1 = y1 - c1, f2 = y2 - c2, word[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t w = 0;
+                if (coded[k]) {
+                    int dr = 0, dg = 0, db = 0;
+                    const uint32_t v = nl[k];
+                    if (v) {
+                        const uint32_t f = cinc[k][0] ? f0 : (cinc[k][1] ? f1 : f2);
+                        const uint32_t kk = s_base[wv][v] + ((f >> csh[k]) & 1023u);
+                        const uint8_t *st = sc + s_off[v];
+                        uint32_t zr, zg, zb;
+                        if (v == 1) { const uint32_t b = st[kk]; zr = b >> 2; zg = (b >> 1) & 1; zb = b & 1; }
+                        else if (v == 2) { const uint32_t b = st[kk]; zr = b >> 4; zg = (b >> 2) & 3; zb = b & 3; }
+                        else { zr = st[3 * kk]; zg = st[3 * kk + 1]; zb = st[3 * kk + 2]; }
+                        dr = zz_dec((int)zr); dg = zz_dec((int)zg); db = zz_dec((int)zb);
+                    }
+                    uint32_t x = px + k, y = py;
+                    if (x >= t.w) { x -= t.w; y++; }   // (tiles at least 4 wide: one wrap at most; narrower tiles below)
+                    if (t.w < 4) { y = (i + k) / t.w; x = (i + k) - y * t.w; }
+                    if (useG && x > 0 && y > 0) { dr += dg; db += dg; }
+                    w = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) | (1u << 24);
                 }
-                const uint32_t y = i / t.w, x = i - y * t.w;
-                if (useG && x > 0 && y > 0) { dr += dg; db += dg; }
-                word = ((uint32_t)dr & 255u) | (((uint32_t)dg & 255u) << 8) | (((uint32_t)db & 255u) << 16) | (1u << 24);
+                word[k] = w;
+                f0 += cinc[k][0]; f1 += cinc[k][1]; f2 += cinc[k][2];
             }
-            rs[i] = word;
+            *reinterpret_cast<u32x4_t *>(rs + i) = u32x4_t{word[0], word[1], word[2], word[3]};  // (the residual plane carries slack behind a tile)
         }
         uint32_t tot = 0;
-        if (tid >= 1 && tid < 9) for (int w2 = 0; w2 < THREADS / 64; w2++) tot += s_wave[w2][tid];
-        __syncthreads();
+        if (tid >= 1 && tid < 9) for (int w2 = 0; w2 < WAVES; w2++) tot += s_wave[w2][tid];
+        __syncthreads();  // (C) every wave has read the running and the per-wave counts
         if (tid >= 1 && tid < 9) s_run[tid] += tot;
-        __syncthreads();
+        px += dx; py += dy;
+        if (px >= t.w) { px -= t.w; py++; }
+        // (the next iteration's barrier (A) orders these LDS writes before their next use)
     }
 }
 

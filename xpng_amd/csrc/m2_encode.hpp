@@ -126,8 +126,10 @@ __global__ __launch_bounds__(THREADS) void k_m2_count(const TileDesc *__restrict
 
 // --------------------------------------------------------------------------------------------------
 // routing for colour tiles: context streams by pl (as k_m1_streams) and class streams by nl.  grid = tiles, block = THREADS
-// (1024 for one image: the tile's latency; 256 for batches: four barriers per 256-pixel step cost less among 4 waves than among 16,
-// and eight workgroups share a CU instead of two).
+// (1024 for one image: the tile's latency; 256 for batches).  A lane owns FOUR consecutive pixels (one dword of each plane, read an
+// iteration ahead); the append position of a pixel in its context stream and in its class stream are prefix sums of nine and
+// eight counters, packed three 10-bit fields to a word: six DPP scans per 4 x THREADS pixels (rounds 1-3: one pixel per lane and
+// seventeen ballots per THREADS pixels).  Three barriers per iteration.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
@@ -136,73 +138,124 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
     const uint32_t tile = vtile(sel, blockIdx.x);
     const TileDesc t = tiles[tile];
     if ((flags[tile] & (M2F_NOT_SINGLE | M2F_NOT_GRAY)) != (M2F_NOT_SINGLE | M2F_NOT_GRAY)) return;  // single colour or gray
+    constexpr int WAVES = THREADS / 64, PX = THREADS * 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint8_t *pnl = planes + t.pbase, *pr_ = planes + plane_stride + t.pbase;
-    const uint8_t *pg = planes + 2 * plane_stride + t.pbase, *pb = planes + 3 * plane_stride + t.pbase;
+    const uint32_t *pnl = reinterpret_cast<const uint32_t *>(planes + t.pbase), *pr_ = reinterpret_cast<const uint32_t *>(planes + plane_stride + t.pbase);
+    const uint32_t *pg = reinterpret_cast<const uint32_t *>(planes + 2 * plane_stride + t.pbase), *pb = reinterpret_cast<const uint32_t *>(planes + 3 * plane_stride + t.pbase);
     uint8_t *sc = scratch2 + sbase2[tile];
-    __shared__ uint32_t s_run_ctx[9], s_run_cls[9];
-    __shared__ uint32_t s_off[17];  // places of the 17 streams (their lengths are known: k_m2_count)
-    __shared__ uint32_t s_wave_ctx[THREADS / 64][9], s_wave_cls[THREADS / 64][9];
-    __shared__ uint32_t s_wave_last[THREADS / 64];
+    __shared__ uint32_t s_off[17];                 // places of the 17 streams (their lengths are known: k_m2_count)
+    __shared__ uint32_t s_run_ctx[9], s_run_cls[9];  // symbols routed so far: per context stream; per class, in PIXELS
+    __shared__ uint32_t s_wave_ctx[WAVES][9], s_wave_cls[WAVES][9];
+    __shared__ volatile uint32_t s_bctx[WAVES][16], s_bcls[WAVES][16];
+    __shared__ uint32_t s_wave_last[WAVES];
     if (tid < 9) { s_run_ctx[tid] = 0; s_run_cls[tid] = 0; }
     if (tid < 17) s_off[tid] = (uint32_t)m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, tid);
     __syncthreads();
     uint32_t run_pl = 0;
     const uint64_t lt = lanemask_lt();
-    for (uint32_t i0 = 0; i0 < t.n; i0 += THREADS) {
-        const uint32_t i = i0 + tid;
-        const uint32_t nlv = i < t.n ? pnl[i] : NL_NONE;
-        const bool coded = nlv != NL_NONE;
-        const uint64_t mask = __ballot(coded), lower = mask & lt;
-        const uint32_t wave_last = __shfl(nlv, mask ? 63 - __clzll((long long)mask) : 0);
-        if (lane == 0) s_wave_last[wv] = mask ? wave_last : NL_NONE;
-        const uint32_t prev_in_wave = __shfl(nlv, lower ? 63 - __clzll((long long)lower) : 0);
-        // class rank inside the wave (by nl); class v >= 3 holds 3 symbols per pixel
-        uint32_t cls_rank = 0, cls_cnt = 0;
-#pragma unroll
-        for (uint32_t c = 1; c < 9; c++) {
-            const uint64_t m = __ballot(coded && nlv == c);
-            if (nlv == c) cls_rank = (uint32_t)__popcll(m & lt);
-            if (lane == c) cls_cnt = (uint32_t)__popcll(m);
+    // field of counter c in the packed words: word c / 3, bits [10 * (c % 3), +10)
+    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);
+    uint32_t nx_nl = 0xFFFFFFFFu, nx_r = 0, nx_g = 0, nx_b = 0;
+    if (4 * tid < t.n) { nx_nl = pnl[tid]; nx_r = pr_[tid]; nx_g = pg[tid]; nx_b = pb[tid]; }
+    for (uint32_t i0 = 0; i0 < t.n; i0 += PX) {
+        const uint32_t i = i0 + 4 * tid;
+        uint32_t nl4 = nx_nl;
+        const uint32_t r4 = nx_r, g4 = nx_g, b4 = nx_b;
+        {
+            const uint32_t in = i + PX;
+            nx_nl = 0xFFFFFFFFu;
+            if (in < t.n) { nx_nl = pnl[in >> 2]; nx_r = pr_[in >> 2]; nx_g = pg[in >> 2]; nx_b = pb[in >> 2]; }
         }
-        if (lane >= 1 && lane < 9) s_wave_cls[wv][lane] = cls_cnt;
-        __syncthreads();  // (A)
+        if (i < t.n && t.n - i < 4) nl4 |= 0xFFFFFFFFu << (8 * (t.n - i));  // pixels past the tile: not coded
+        uint32_t nl[4], csh[4], cinc[4][3], c0 = 0, c1 = 0, c2 = 0;
+        bool coded[4];
+        uint32_t lastnl = NL_NONE;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            nl[j] = (nl4 >> (8 * j)) & 255u;
+            coded[j] = nl[j] != NL_NONE;
+            lastnl = coded[j] ? nl[j] : lastnl;
+            // class counter of the pixel: field nl (1..8; nl = 0 emits no class symbol)
+            const uint32_t v = coded[j] ? (nl[j] & 15u) : 0u, q = (v * 11u) >> 5;
+            csh[j] = 10u * (v - 3u * q);
+            const uint32_t one = v ? 1u << csh[j] : 0u;
+            cinc[j][0] = q == 0 ? one : 0u; cinc[j][1] = q == 1 ? one : 0u; cinc[j][2] = q == 2 ? one : 0u;
+            c0 += cinc[j][0]; c1 += cinc[j][1]; c2 += cinc[j][2];
+        }
+        const uint64_t mask = __ballot(nl4 != 0xFFFFFFFFu);
+        const uint64_t lower = mask & lt;
+        const uint32_t wave_last = __shfl(lastnl, mask ? 63 - __clzll((long long)mask) : 0);
+        if (lane == 0) s_wave_last[wv] = mask ? wave_last : NL_NONE;
+        const uint32_t prev_in_wave = __shfl(lastnl, lower ? 63 - __clzll((long long)lower) : 0);
+        const uint32_t y0 = wave_scan_incl(c0), y1 = wave_scan_incl(c1), y2 = wave_scan_incl(c2);
+        {
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)y0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)y1, 63),
+                           t2 = (uint32_t)__builtin_amdgcn_readlane((int)y2, 63);
+            const uint32_t word = myq == 0 ? t0 : (myq == 1 ? t1 : t2);
+            if (lane < 9) s_wave_cls[wv][lane] = (word >> mysh) & 1023u;
+        }
+        __syncthreads();  // (A) wave_last / class counts visible
         uint32_t carry = run_pl, new_run_pl = run_pl;
-        for (int w2 = 0; w2 < THREADS / 64; w2++) {
+        for (int w2 = 0; w2 < WAVES; w2++) {
             const uint32_t wl = s_wave_last[w2];
             if (w2 < (int)wv && wl != NL_NONE) carry = wl;
             if (wl != NL_NONE) new_run_pl = wl;
         }
-        const uint32_t pl = lower ? prev_in_wave : carry;
-        uint32_t ctx_rank = 0, ctx_cnt = 0;
+        uint32_t pl[4], sh[4], inc[4][3], w0 = 0, w1 = 0, w2s = 0;
+        {
+            uint32_t p = lower ? prev_in_wave : carry;
 #pragma unroll
-        for (uint32_t c = 0; c < 9; c++) {
-            const uint64_t m = __ballot(coded && pl == c);
-            if (pl == c) ctx_rank = (uint32_t)__popcll(m & lt);
-            if (lane == c) ctx_cnt = (uint32_t)__popcll(m);
-        }
-        if (lane < 9) s_wave_ctx[wv][lane] = ctx_cnt;
-        __syncthreads();  // (B)
-        if (coded) {
-            uint32_t base = s_run_ctx[pl];
-            for (uint32_t w2 = 0; w2 < wv; w2++) base += s_wave_ctx[w2][pl];
-            sc[s_off[pl] + base + ctx_rank] = (uint8_t)nlv;
-            if (nlv) {
-                uint32_t cb = s_run_cls[nlv];
-                for (uint32_t w2 = 0; w2 < wv; w2++) cb += s_wave_cls[w2][nlv];
-                uint8_t *dst = sc + s_off[8 + nlv];
-                const uint32_t zr = pr_[i], zg = pg[i], zb = pb[i];
-                if (nlv == 1) dst[cb + cls_rank] = (uint8_t)((zr << 2) | (zg << 1) | zb);        // libxpng.c:37
-                else if (nlv == 2) dst[cb + cls_rank] = (uint8_t)((zr << 4) | (zg << 2) | zb);   // libxpng.c:38
-                else { uint8_t *q = dst + 3 * (cb + cls_rank); q[0] = (uint8_t)zr; q[1] = (uint8_t)zg; q[2] = (uint8_t)zb; }  // :39
+            for (int j = 0; j < 4; j++) {
+                pl[j] = p;
+                const uint32_t q = (p * 11u) >> 5;
+                sh[j] = 10u * (p - 3u * q);
+                const uint32_t one = coded[j] ? 1u << sh[j] : 0u;
+                inc[j][0] = q == 0 ? one : 0u; inc[j][1] = q == 1 ? one : 0u; inc[j][2] = q == 2 ? one : 0u;
+                w0 += inc[j][0]; w1 += inc[j][1]; w2s += inc[j][2];
+                p = coded[j] ? nl[j] : p;
             }
         }
+        const uint32_t x0 = wave_scan_incl(w0), x1 = wave_scan_incl(w1), x2 = wave_scan_incl(w2s);
+        {
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, 63),
+                           t2 = (uint32_t)__builtin_amdgcn_readlane((int)x2, 63);
+            const uint32_t word = myq == 0 ? t0 : (myq == 1 ? t1 : t2);
+            if (lane < 9) s_wave_ctx[wv][lane] = (word >> mysh) & 1023u;
+        }
+        __syncthreads();  // (B) per-wave context counts visible
+        if (lane < 9) {   // this wave's base position in each context stream (bytes inside the tile's scratch) and in each class (pixels)
+            uint32_t bc = s_off[lane] + s_run_ctx[lane], bk = s_run_cls[lane];
+            for (uint32_t w = 0; w < wv; w++) { bc += s_wave_ctx[w][lane]; bk += s_wave_cls[w][lane]; }
+            s_bctx[wv][lane] = bc; s_bcls[wv][lane] = bk;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t e0 = x0 - w0, e1 = x1 - w1, e2 = x2 - w2s;  // exclusive lane prefixes, advanced pixel by pixel
+        uint32_t f0 = y0 - c0, f1 = y1 - c1, f2 = y2 - c2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (coded[j]) {
+                const uint32_t e = inc[j][0] ? e0 : (inc[j][1] ? e1 : e2);
+                sc[s_bctx[wv][pl[j]] + ((e >> sh[j]) & 1023u)] = (uint8_t)nl[j];
+                const uint32_t v = nl[j];
+                if (v) {
+                    const uint32_t f = cinc[j][0] ? f0 : (cinc[j][1] ? f1 : f2);
+                    const uint32_t k = s_bcls[wv][v] + ((f >> csh[j]) & 1023u);
+                    uint8_t *dst = sc + s_off[8 + v];
+                    const uint32_t zr = (r4 >> (8 * j)) & 255u, zg = (g4 >> (8 * j)) & 255u, zb = (b4 >> (8 * j)) & 255u;
+                    if (v == 1) dst[k] = (uint8_t)((zr << 2) | (zg << 1) | zb);        // libxpng.c:37
+                    else if (v == 2) dst[k] = (uint8_t)((zr << 4) | (zg << 2) | zb);   // libxpng.c:38
+                    else { uint8_t *q = dst + 3 * k; q[0] = (uint8_t)zr; q[1] = (uint8_t)zg; q[2] = (uint8_t)zb; }  // :39
+                }
+            }
+            e0 += inc[j][0]; e1 += inc[j][1]; e2 += inc[j][2];
+            f0 += cinc[j][0]; f1 += cinc[j][1]; f2 += cinc[j][2];
+        }
         uint32_t tot_ctx = 0, tot_cls = 0;
-        if (tid < 9) for (int w2 = 0; w2 < THREADS / 64; w2++) { tot_ctx += s_wave_ctx[w2][tid]; if (tid) tot_cls += s_wave_cls[w2][tid]; }
-        __syncthreads();  // (C)
+        if (tid < 9) for (int w2 = 0; w2 < WAVES; w2++) { tot_ctx += s_wave_ctx[w2][tid]; tot_cls += s_wave_cls[w2][tid]; }
+        __syncthreads();  // (C) every wave has read the running counts and the per-wave counts
         if (tid < 9) { s_run_ctx[tid] += tot_ctx; s_run_cls[tid] += tot_cls; }
         run_pl = new_run_pl;
-        __syncthreads();
+        // (the next iteration's barrier (A) orders these LDS writes before their next use)
     }
 }
 
