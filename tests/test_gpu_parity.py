@@ -619,6 +619,53 @@ def test_device_side_size_walk(gpu, po):
         ctx.close()
 
 
+def test_level2_stream_counts_that_do_not_fit_together_are_rejected(gpu, po):
+    """Level-2 decode: the 17 decoded streams of a tile lie back to back in a region sized for what a real tile can hold (n - 1
+    context symbols, 3 (n - 1) class symbols), each in the room its block header's symbol count asks for.  A file whose class
+    blocks EACH claim the per-stream maximum passes the per-stream bound the format gives and must still be rejected - before any
+    chain writes a byte - and the untouched file must decode afterwards."""
+    import torch
+    from xpng_amd.synth import synth_raster
+    W, H = 420, 300                                   # one tile
+    raster = synth_raster("photo", W, H, False, seed=9)
+    ctx = gpu.Context(W, H, 3)
+    assert ctx.n_tiles == 1
+    n = W * H
+    good = po.encode_tiles(2, raster)
+    u32 = lambda b, o: int.from_bytes(b[o:o + 4], "little")
+    assert (u32(good, 0) >> 28) == 1                  # a colour tile (libxpng.c:929-961)
+    bsz = u32(good, 4)
+    o, heads = 4 + bsz, []
+    for slot in range(17):                            # the 17 block headers behind the shared bit stream
+        hdr = u32(good, o)
+        heads.append((slot, o, hdr >> 24, hdr & 0xFFFFFF))
+        o += hdr & 0xFFFFFF
+    assert o == (u32(good, 0) & 0xFFFFFF)
+    bad = bytearray(good)
+    grown = 0
+    for slot, off, typ, size in heads:
+        if slot >= 11 and typ in (3, 4):              # class >= 3 streams: 3 n symbols is the most the format allows one of them
+            bad[off + 4:off + 8] = (3 * n).to_bytes(4, "little")
+            grown += 1
+    assert grown >= 2
+    d_o = torch.zeros(n * 3 + 64, dtype=torch.uint8, device="cuda")
+    for force_wide in (False, True):
+        if force_wide:
+            os.environ["XPNG_WIDE_RANS"] = "1"
+        try:
+            d_b = torch.zeros(len(bad) + 64, dtype=torch.uint8, device="cuda")
+            d_b[: len(bad)] = torch.frombuffer(bytearray(bad), dtype=torch.uint8).cuda()
+            ctx.decode_device(2, d_b.data_ptr(), len(bad), [0], d_o.data_ptr())
+            assert ctx.decode_status() == 1
+            d_b[: len(good)] = torch.frombuffer(bytearray(good), dtype=torch.uint8).cuda()
+            ctx.decode_device(2, d_b.data_ptr(), len(good), [0], d_o.data_ptr())
+            assert ctx.decode_status() == 0
+            assert np.array_equal(d_o[: n * 3].cpu().numpy().reshape(H, W, 3), raster)
+        finally:
+            os.environ.pop("XPNG_WIDE_RANS", None)
+    ctx.close()
+
+
 @pytest.mark.parametrize("T", [2, 3])
 def test_worker_count_T_shards_tile_ranges_over_devices(gpu, po, tmp_path, monkeypatch, T):
     """xpng_store_T / xpng_load_T with T > 1 (reference libxpng.c:146-151: T workers over the tile cursor): T devices of one
