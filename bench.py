@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- xPNG hot path on MI355X: Mpixels/s encode+decode, bit-exact vs the reference.
 
-  python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 is one process per GPU over torch.distributed (RCCL).  Run under `python -m torch.distributed.run --nproc-per-node N ...`
+the script is rank RANK of WORLD_SIZE; run PLAIN with --gpus N > 1 (no WORLD_SIZE in the environment) it starts the N ranks
+itself - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a child process, before
+anything here touches the GPU - relays rank 0's JSON line and exits with the child's code.  A WORLD_SIZE that is not N is an
+error: the line never reports an n_gpus other than the one asked for.
 
 A step = one pass of the hot path over one batch of synthetic rasters already resident in HBM:
     tile ENCODE (rasters -> concatenated tile blobs)  [+ RCCL exchange of blob ranges when N>1]
@@ -119,6 +125,68 @@ def ctx_len_at(ctx, i):
     return hip_lib().xpnghip_ctx_last_blobs_len_at(ctx._h, i)
 
 
+def spawn_ranks(args, argv):
+    """--gpus N > 1 run plainly (no WORLD_SIZE): start the N ranks as a CHILD torch.distributed.run (never an exec: this process may
+    not have touched the GPU yet, but a launcher must not rely on that), relay its output, return its exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    ok = False
+    for ln in out.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, flush=True)
+    if lines:
+        try:
+            ok = json.loads(lines[-1]).get("n_gpus") == args.gpus
+        except Exception:
+            ok = False
+        print(lines[-1], flush=True)
+    if out.returncode == 0 and not ok:
+        print(f"bench.py: the {args.gpus}-rank child did not report n_gpus == {args.gpus}", file=sys.stderr)
+        return 3
+    return out.returncode
+
+
+def newest_profile(pattern):
+    """newest committed profiles/rNN_*<pattern> (by round number, then name)"""
+    import glob
+    best = None
+    for fn in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*" + pattern)):
+        key = (os.path.basename(fn)[:3], os.path.basename(fn))
+        if best is None or key > best[0]:
+            best = (key, fn)
+    return best[1] if best else None
+
+
+def step_roofline_obj(res):
+    """The WHOLE step against the HBM roofline: algorithmic bytes of an encode + decode of one pixel = read PXSZ +
+    write the compressed bytes (encode), read them + write PXSZ (decode): SURVEY.md 8(d); achieved = that x pixels per step /
+    ms_per_step.  traffic_* = what the counters saw for one step (newest profiles/*pmc_step_mem*.json of this pixel format)."""
+    ch, level = res["ch"], res["level"]
+    px_img = res["W"] * res["H"]
+    algo = 2.0 * ch + 2.0 * res["compressed_bytes"] / px_img
+    achieved = algo * res["B"] * res["my_px"] / (res["ms_per_step"] * 1e-3) / 1e9
+    out = {"bound": "hbm", "algorithmic_bytes_per_px": round(algo, 3), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic_bytes_per_px": None, "traffic_over_algorithmic": None, "traffic_source": None}
+    fn = newest_profile("pmc_step_mem.json" if ch == 4 and level == 1 else ("pmc_step_mem_rgb.json" if level == 1 else "pmc_step_mem_rgb_l2.json"))
+    if fn:
+        try:
+            pmc = json.load(open(fn))
+            out["traffic_bytes_per_px"] = pmc["bytes_per_px"]
+            out["traffic_over_algorithmic"] = round(pmc["bytes_per_px"] / algo, 2)
+            out["traffic_source"] = "profiles/" + os.path.basename(fn) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one step, serialised passes)"
+        except Exception:
+            pass
+    return out
+
+
 class Env:
     """process-wide state of one bench run (rank, device, backend)"""
     def __init__(self, args):
@@ -128,8 +196,8 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus and self.world > 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: refusing to print a line for another rank count")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the xPNG tile codec has no CPU fallback")
         self.local_rank = local_rank % torch.cuda.device_count()  # (a rehearsal may run several ranks on one GPU)
@@ -296,6 +364,15 @@ def run_leg(env, W, H, alpha, level, B, P, steps, warmup, kind="photo", roofline
                 del back
                 assert ok_back
             res["api_enc_ms"], res["api_dec_ms"] = best_e * 1e3, best_d * 1e3
+            # ... and what xpng_store itself runs on the caller's raw raster (host/xpng_api.c store_on_device): xpnghip_image_begin
+            # (upload + normalize_RGBA on the device) -> xpnghip_image_encode_T -> xpnghip_image_end, memory to memory: the
+            # reference's own timed region (libxpng.c:727-760: validation, normalize_RGBA, the tile stage; no file output)
+            best_s = 1e9
+            for _ in range(5):
+                t_a = time.perf_counter(); mb = api.image_store(level, host_r); best_s = min(best_s, time.perf_counter() - t_a)
+                assert mb.n == len(blobs_h) and mb.bytes() == blobs_h
+                mb.free()
+            res["store_ms"] = best_s * 1e3
             # the host-buffer calls keep their contexts (three pipeline shards, each with streams of its own) in the library's pool of
             # idle ones; give them back before the pipelined steps: HIP maps streams onto the 32 hardware queues as they are created,
             # and with more streams alive than queues the slots' streams start sharing queues, i.e. serialising (measured: 38.5 -> 35)
@@ -382,7 +459,26 @@ def main():
                          "sequence (the entropy stage is a serial chain per tile stream, so one image alone cannot fill 256 CUs)")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="experiment: host sleep between the first steps of the pipeline slots (warm-up), so that their cycles start apart; 0 = off")
     ap.add_argument("--probe-run", action="store_true", help="tools only: load libxpng_hip_probes.so and accept timing-study switches; the line is marked probe_run and is not a benchmark")
+    ap.add_argument("--spawn-check", action="store_true", help="CPU rehearsal of the rank start-up only: the ranks rendezvous (gloo), agree on the world size and rank 0 prints a line with n_gpus and spawn_check: true; no GPU is touched and nothing is measured")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))  # (before anything initialises the GPU in this process)
+    if args.spawn_check:
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        if world > 1:
+            import torch
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "SPAWN CHECK, not a benchmark", "spawn_check": True, "n_gpus": world, "value": None}), flush=True)
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
     env_seen = env_report(args.probe_run)
     if args.level == 2 and not args.rgb:
         raise SystemExit("--level 2 codes RGB only (libxpng.c:755 sends RGBA to level 1): add --rgb")
@@ -427,7 +523,7 @@ def main():
                               "batch": c["config"]["batch"], "pipeline_slots": c["config"]["pipeline_slots"], "compressed_bytes": c["config"]["compressed_bytes"],
                               "verified": c["verified"], "hbm_in_use_gb": c["config"]["hbm_in_use_gb"],
                               "single_image_encode_ms": c["single_image_encode_ms"], "single_image_decode_ms": c["single_image_decode_ms"],
-                              "single_image": c["single_image"], "roofline": c["roofline"], "cpu_baseline": c["cpu_baseline"],
+                              "single_image": c["single_image"], "roofline": c["roofline"], "step_roofline": c.get("step_roofline"), "cpu_baseline": c["cpu_baseline"],
                               "command": "python bench.py " + " ".join(cmd[2:])}
             except Exception as ex:  # a leg that cannot be measured is reported as such, never silently dropped
                 legs[name] = {"error": f"{type(ex).__name__}: {ex}"}
@@ -486,6 +582,7 @@ def main():
                        "hbm_in_use_gb": r["hbm_in_use_gb"], "env": env_seen, "library": os.path.basename(lib_name)},
             "verified": r["verified"],
             "roofline": roofline_obj(r),
+            "step_roofline": step_roofline_obj(r),
             "cpu_baseline": cpu,
         }
         # ONE image through the boundary's own entry points, beside the reference doing the same call on this node's CPUs.
@@ -495,13 +592,17 @@ def main():
               "on_device_encode_ms": round(r["enc_ms"], 3), "on_device_decode_ms": round(r["dec_ms"], 3),
               "on_device_encode_mpx_s": round(r["my_px"] / r["enc_ms"] / 1e3, 1), "on_device_decode_mpx_s": round(r["my_px"] / r["dec_ms"] / 1e3, 1)}
         if "api_enc_ms" in r:
-            si.update({"api_encode_ms": round(r["api_enc_ms"], 3), "api_decode_ms": round(r["api_dec_ms"], 3),
-                       "api_encode_mpx_s": round(r["my_px"] / r["api_enc_ms"] / 1e3, 1), "api_decode_mpx_s": round(r["my_px"] / r["api_dec_ms"] / 1e3, 1),
-                       "api": "xpnghip_encode_tiles / xpnghip_decode_tiles (what xpng_store / xpng_load call): host buffers, H2D + kernels + D2H, the C call alone (decode into a freshly malloc()ed raster), best of 5"})
+            si.update({"store_ms": round(r["store_ms"], 3), "load_ms": round(r["api_dec_ms"], 3),
+                       "store_mpx_s": round(r["my_px"] / r["store_ms"] / 1e3, 1), "load_mpx_s": round(r["my_px"] / r["api_dec_ms"] / 1e3, 1),
+                       "store_load": "what xpng_store / xpng_load execute between their clocks, memory to memory on the caller's host buffers, the C calls alone, best of 5: "
+                                     "store = xpnghip_image_begin (upload + normalize_RGBA on the device) -> xpnghip_image_encode_T -> xpnghip_image_end "
+                                     "(host/xpng_api.c store_on_device; the reference's region libxpng.c:727-760); load = xpnghip_decode_tiles into a freshly malloc()ed raster (libxpng.c:967-985)",
+                       "raw_entry_encode_ms": round(r["api_enc_ms"], 3),
+                       "raw_entry": "xpnghip_encode_tiles alone on an already normalised raster (the raw entry point; xpng_store does not call it)"})
             if cpu:
                 si["reference_cpu_encode_ms"], si["reference_cpu_decode_ms"] = cpu["encode_ms"], cpu["decode_ms"]
-                si["api_vs_reference_cpu"] = {"encode": round(cpu["encode_ms"] / r["api_enc_ms"], 3), "decode": round(cpu["decode_ms"] / r["api_dec_ms"], 3),
-                                              "note": "ratio > 1 = this library faster than the reference's CPU call for ONE image; < 1 = slower"}
+                si["api_vs_reference_cpu"] = {"encode": round(cpu["encode_ms"] / r["store_ms"], 3), "decode": round(cpu["decode_ms"] / r["api_dec_ms"], 3),
+                                              "note": "store_ms / load_ms against the reference's CPU call for ONE image (same timed regions); ratio > 1 = this library faster, < 1 = slower"}
         out["single_image"] = si
         out["single_image_encode_ms"], out["single_image_decode_ms"] = si["on_device_encode_ms"], si["on_device_decode_ms"]
         out["single_image_encode_mpx_s"], out["single_image_decode_mpx_s"] = si["on_device_encode_mpx_s"], si["on_device_decode_mpx_s"]

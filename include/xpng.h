@@ -38,8 +38,8 @@ XPNG_CHECK _Bool xpng_from_jpg(const char *jpg, const char *xpng);
 /* reference xpng.h:17-20 (libxpng.c:723, 963, 1004).  T = worker count (libxpng.c:146-151); here the workers are the GPUs
  * of this process: T >= 1 uses min(T, visible GPUs, tiles) devices, each coding one contiguous tile range, the blob ranges
  * gathered on the first device for the concatenation; T == 0 (what xpng_store / xpng_load pass, the reference's "nproc")
- * picks as many as leave each device at least 256 tiles, i.e. one GPU for anything below ~7000 x 7000 pixels.  The output
- * bytes do not depend on T. */
+ * is ONE device (XPNG_GPUS=n in the environment: n): the multi-device form is opt-in until a byte-parity run on real peer
+ * GPUs exists (include/xpng_hip.h says the same).  The output bytes do not depend on T. */
 XPNG_CHECK _Bool xpng_store_T(uint64_t T, uint64_t mode, const xpng_t *pm, const char *xpng);
 XPNG_CHECK _Bool xpng_load_T(uint64_t T, const char *xpng, xpng_t *pm);
 XPNG_CHECK _Bool xpng_from_jpg_T(uint64_t T, const char *jpg, const char *xpng);

@@ -79,10 +79,13 @@ def test_libraries_load_and_report_no_device_without_gpu():
 
 
 def test_gfx950_code_object_is_embedded():
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={api.HIP_SO}"],
-                         capture_output=True, text=True)
-    blob = open(api.HIP_SO, "rb").read()
-    assert b"gfx950" in blob and (out.returncode != 0 or "gfx950" in out.stdout or True)
+    """The fat binary inside both flavours of the HIP library holds exactly one device code object, and it is gfx950's: the
+    offload bundle's entry id (`hipv4-amdgcn-amd-amdhsa--gfx950`) is in the .hip_fatbin section, and no other gfx target is."""
+    import re
+    for so in (api.HIP_SO, api.PROBES_SO):
+        blob = open(so, "rb").read()
+        ids = set(re.findall(rb"hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+        assert ids == {b"gfx950"}, (so, ids)
 
 
 def test_no_compute_without_device_fails_loudly():

@@ -945,3 +945,46 @@ def test_band_reconstruction_row_staging_at_every_alignment(gpu, po, monkeypatch
         assert np.array_equal(out[64 + shift:64 + shift + nbytes].reshape(H, W, ch), raster), (geom, shift)
         assert (out[:64 + shift] == 0xA5).all() and (out[64 + shift + nbytes:] == 0xA5).all(), (geom, shift)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["translucent_last_band", "hidden_late", "opaque", "rgb", "rgba_level2"])
+def test_xpng_store_band_pipeline(gpu, po, tmp_path, case):
+    """xpng_store on an ordinary large raster stages it in three tile-row bands, each on a stream of its own: upload ->
+    normalize_RGBA flags -> hidden colours zeroed in place -> the band's tile encode (wrappers.hpp, staged image [r4]; the
+    reference's serial pre-pass is libxpng.c:688-721, inside its timed region 727-760).  The only whole-image decision - the
+    raster stays RGBA iff some pixel has alpha != 255 - is taken at the first band that holds such a pixel.  Odd widths put the
+    bands at every 16-byte phase.  Every file equals the oracle's, and xpng_load returns the normalised raster."""
+    from xpng_amd.synth import synth_raster
+    w, h = 3001, 2999                     # 36 MB as RGBA, 27 MB as RGB: seven tile rows, three bands
+    level = 1
+    if case == "rgb":
+        r = synth_raster("photo", w, h, False, seed=5)
+        level = 2
+    else:
+        r = synth_raster("photo", w, h, True, seed=5)
+        if case == "opaque":
+            r[..., 3] = 255                                   # no translucent pixel anywhere: repacked to RGB after the last band
+        elif case == "translucent_last_band":
+            r[..., 3] = 255
+            r[h - 3, w - 2, 3] = 254                          # ... except one, in the last band: stays RGBA, decided late
+        elif case == "hidden_late":
+            r[..., 3] = 255
+            r[5, 7, 3] = 17                                   # band 0 settles "RGBA" at once; hidden colours exist only further down
+            r[h // 2, 11] = (9, 8, 7, 0)
+            r[h - 1, w - 1] = (1, 0, 0, 0)
+        elif case == "rgba_level2":
+            level = 2                                         # RGBA at level 2: the single-colour test runs first (whole raster), then level 1
+    want = po.encode_image(level, r)
+    out = tmp_path / "o.xpng"
+    gpu.store(level, r, str(out))
+    data = out.read_bytes()
+    assert len(data) == len(want) and data == want, case
+    back = gpu.load(str(out))
+    norm = po.normalize_rgba(r) if r.shape[2] == 4 else r
+    assert back.shape == norm.shape and np.array_equal(back, norm), case
+    # the same raster again through a pooled staging object (buffers and streams reused), and a small one behind it (whole-image form)
+    gpu.store(level, r, str(out))
+    assert out.read_bytes() == want
+    small = np.ascontiguousarray(r[:300, :400])
+    gpu.store(level, small, str(out))
+    assert out.read_bytes() == po.encode_image(level, small)

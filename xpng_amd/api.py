@@ -261,6 +261,24 @@ def staged_encode(mode: int, raster: np.ndarray, T: int = 1, lib=None):
         lib.xpnghip_image_end(img)
 
 
+def image_store(mode: int, raster: np.ndarray, T: int = 0, lib=None) -> MallocedBlobs:
+    """Exactly the device-side sequence of xpng_store for a raster that reaches the tile codec (host/xpng_api.c store_on_device):
+    xpnghip_image_begin -> xpnghip_image_encode_T -> xpnghip_image_end.  Returns the library's malloc()ed blob buffer."""
+    raster = np.ascontiguousarray(raster, dtype=np.uint8)
+    h, w, ch = raster.shape
+    lib = lib or hip_lib()
+    img, pxsz = C.c_void_p(), C.c_int(0)
+    if lib.xpnghip_image_begin(C.byref(img), raster.ctypes.data_as(C.c_void_p), w, h, ch, C.byref(pxsz)):
+        raise XpngError("xpnghip_image_begin: " + lib.xpnghip_last_error().decode(errors="replace"))
+    try:
+        p, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+        if lib.xpnghip_image_encode_T(img, T, mode, C.byref(p), C.byref(n)):
+            raise XpngError("xpnghip_image_encode_T: " + lib.xpnghip_last_error().decode(errors="replace"))
+        return MallocedBlobs(p, n.value)
+    finally:
+        lib.xpnghip_image_end(img)
+
+
 def store(mode: int, raster: np.ndarray, path: str, T: int = None) -> None:
     """xpng_store[_T] (include/xpng.h): full host driver incl. normalisation, fallbacks and file output."""
     raster = np.ascontiguousarray(raster, dtype=np.uint8)

@@ -21,6 +21,7 @@ inline const char *probe_env(const char *name) { return getenv(name); }
 #else
 inline const char *probe_env(const char *) { return nullptr; }
 #endif
+int user_hw_queues();  // GPU_MAX_HW_QUEUES as the CALLER exported it (0: not at all); xpng_hip.hip
 inline size_t probe_pad(const char *name) { const char *v = probe_env(name); return v ? (size_t)atoi(v) : 0; }  // bytes of unused dynamic LDS (occupancy throttle)
 
 // Streams that carry serial-chain kernels.  tools/wave_probe.py shows that in the pipelined bench the chain WAVES run at their solo
@@ -122,7 +123,7 @@ __host__ __device__ inline uint32_t imglin(const TileSel &s, uint32_t vt) { cons
 // device: the alpha chains start while the routing kernel is still running).  The nine context streams share the tile's
 // n - 1 coded pixels, and how they share them is known BEFORE the routing kernel writes a byte: stream c receives the nl of
 // every coded pixel whose predecessor's nl is c, so its length is hist[c] - [c == nl of the last coded pixel] + [c == 0], a
-// histogram of the nl plane (k_m1_count).  So each stream gets the room its length needs (+ slack for the 16-byte block loads
+// histogram of the nl plane (taken by the transform as it writes the plane: nlacc_* / k_m1_lens, m1_encode.hpp).  So each stream gets the room its length needs (+ slack for the 16-byte block loads
 // of the chains) and the region is n + 9 * 96 bytes, not nine times n: 7.5 instead of 15.5 bytes of scratch per pixel.
 //   rANS v2 block   : 12 B header + ceil(m*pb/32) words + 16 B states + table (<= 256*16 bits), m = symbols of the stream
 __host__ __device__ inline uint64_t rup(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -213,6 +214,17 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1 and 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {  // inclusive running maximum over the 64 lanes, DPP only (lane 63 = the wave's)
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
     return v;
 }
 

@@ -972,11 +972,22 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
 // residual extraction.  Walks the tile's pixels in raster order, 1024 per step: coded flag (alpha != 0),
 // coded index = running count, bit cursor = running sum of 3*nl; pulls 3*nl bits out of k, undoes zig-zag
 // and the green subtraction, and stores one packed word per pixel: r | g<<8 | b<<16 | coded<<24.
-template <int PXSZ, int THREADS>
+//
+// FOLD [r4] (RGBA, every tile at least 4 pixels wide): the alpha plane is never materialised.  Through round 3 k_dec_alpha turned the
+// alpha symbols into a plane (1 B/px read, 1 B/px written, 2.6 B/px by the counters) that this kernel read back; now it takes the
+// symbols themselves.  alpha(x, y) = alpha(0, y) + sum of the row's deltas up to x, alpha(0, y) = a0 + sum of column 0's deltas up to
+// y (libxpng.c:798-800: left neighbour everywhere except column 0), all mod 256.  A prologue scans column 0 (h strided symbols) into
+// the tile's first h bytes of the `alpha` buffer (scratch now); in the raster-order walk every row start is a "head" whose alpha is
+// that absolute value, every other pixel adds its delta to a running sum P that is NEVER reset:
+//     alpha(pixel) = P(pixel) + H,   H = (alpha - P) at the latest head at or before the pixel
+// so one plain prefix sum (P) and one "latest head" propagation (a running maximum of (lane + 1) << 8 | H over the wave) do it; across
+// waves and iterations two bytes are carried (P and H).  One more barrier per iteration than the plane-reading form.
+template <int PXSZ, int THREADS, bool FOLD = false>
 __global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict__ info,
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
-                                                    const uint8_t *__restrict__ alpha, const uint8_t *__restrict__ nlseq,
+                                                    uint8_t *__restrict__ alpha, const uint8_t *__restrict__ asym, const uint8_t *__restrict__ nlseq,
                                                     uint32_t *__restrict__ resid, uint32_t j0) {
+    static_assert(!FOLD || PXSZ == 4, "only RGBA tiles carry alpha");
     // One workgroup walks a tile in raster order, THREADS * 4 pixels per iteration; a lane owns 4 consecutive pixels: one
     // dword of the alpha plane (read one iteration ahead), up to 4 consecutive nl symbols, up to 96 bits of k, one 16-byte
     // store of residual words.  Two wave scans (coded pixels, bit lengths) and two barriers per iteration.
@@ -994,17 +1005,102 @@ __global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict
     const bool useG = d.type & 1;
     constexpr uint32_t NW = THREADS / 64, PX = THREADS * 4;
     __shared__ uint32_t s_wc[2][NW], s_wb[2][NW];
+    __shared__ uint32_t s_wa[2][NW];  // FOLD: per wave: sum of its deltas | H of its last head << 8 | "has a head" << 16
+    __shared__ uint32_t s_colw[NW], s_colc;
     uint32_t run_cnt = 0, run_bits = 8 * PXSZ, par = 0;
-    // (x, y) of the lane's first pixel, advanced by PX pixels per iteration (only the green add-back needs it: tiles >= 4 wide)
+    // (x, y) of the lane's first pixel, advanced by PX pixels per iteration (the green add-back and the row starts of FOLD need it)
     uint32_t py = (4 * tid) / t.w, px = 4 * tid - py * t.w;
     const uint32_t dy = PX / t.w, dx = PX - dy * t.w;
 
+    // ---- FOLD: column 0 into c0[0 .. h), then the symbol dwords and the head value of the first iteration
+    const uint8_t *sy = FOLD ? asym + t.pbase : nullptr;               // sy[i - 1] = symbol of pixel i
+    const uint32_t *sy4 = reinterpret_cast<const uint32_t *>(sy);
+    uint8_t *c0 = alpha + t.pbase;
+    uint32_t carryP = 0, carryH = 0, nx_cur = 0, nx_prev = 0, nx_A = 0;
+    // head of a lane whose first pixel is (x, y) with tile index i: position hk inside the lane's four pixels and its row
+    auto head_of = [&](uint32_t x, uint32_t y, uint32_t i, uint32_t &hk, uint32_t &hy) __attribute__((always_inline)) -> bool {
+        hk = x == 0 ? 0u : t.w - x; hy = x == 0 ? y : y + 1;
+        return (x == 0 || x + 4 > t.w) && i + hk < t.n;
+    };
+    if (FOLD) {
+        const uint32_t a0 = ld32u(d.blob + 8) & 0xFF;  // first pixel's alpha: 4th byte of the first k word (MSB-first R,G,B,A)
+        if (tid == 0) { s_colc = a0; c0[0] = (uint8_t)a0; }
+        __syncthreads();
+        for (uint32_t y0 = 1; y0 < t.h; y0 += THREADS) {
+            const uint32_t y = y0 + tid;
+            const uint32_t dv = y < t.h ? (uint32_t)zz_dec(sy[(uint64_t)y * t.w - 1]) & 255u : 0u;
+            const uint32_t incl = wave_scan_incl(dv);
+            if (lane == 63) s_colw[wv] = incl;
+            __syncthreads();
+            uint32_t base = s_colc;
+            for (uint32_t w2 = 0; w2 < wv; w2++) base += s_colw[w2];
+            if (y < t.h) c0[y] = (uint8_t)(base + incl);
+            __syncthreads();
+            if (tid == THREADS - 1) s_colc = (base + incl) & 255u;
+            __syncthreads();
+        }
+        __threadfence_block();  // c0[] is read back below by other waves of this workgroup
+        __syncthreads();
+        if (4 * tid < t.n) {
+            nx_cur = sy4[tid]; nx_prev = tid ? sy4[tid - 1] : 0u;
+            uint32_t hk, hy;
+            if (head_of(px, py, 4 * tid, hk, hy)) nx_A = c0[hy];
+        }
+    }
+
     uint32_t nx_a = 0;
-    if (PXSZ == 4 && 4 * tid < t.n) nx_a = al[tid];
+    if (PXSZ == 4 && !FOLD && 4 * tid < t.n) nx_a = al[tid];
     for (uint32_t i0 = 0; i0 < t.n; i0 += PX, par ^= 1) {
         const uint32_t i = i0 + 4 * tid;
         uint32_t a4 = PXSZ == 4 ? nx_a : 0x01010101u;
-        if (PXSZ == 4) { const uint32_t in = i + PX; nx_a = 0; if (in < t.n) nx_a = al[in >> 2]; }
+        if (PXSZ == 4 && !FOLD) { const uint32_t in = i + PX; nx_a = 0; if (in < t.n) nx_a = al[in >> 2]; }
+        if (FOLD) {
+            const uint32_t cur = nx_cur, prev = nx_prev, A = nx_A;
+            uint32_t hk, hy;
+            const bool has_head = head_of(px, py, i, hk, hy);
+            {   // the next iteration's symbol dwords and head value
+                const uint32_t in = i + PX;
+                uint32_t npx = px + dx, npy = py + dy;
+                if (npx >= t.w) { npx -= t.w; npy++; }
+                nx_cur = 0; nx_prev = 0; nx_A = 0;
+                if (in < t.n) {
+                    nx_cur = sy4[in >> 2]; nx_prev = sy4[(in >> 2) - 1];
+                    uint32_t nhk, nhy;
+                    if (head_of(npx, npy, in, nhk, nhy)) nx_A = c0[nhy];
+                }
+            }
+            // deltas of pixels i .. i+3 (symbol of pixel i sits at sy[i-1]); a head and the pixels past the tile add nothing to P
+            const uint32_t u = __builtin_amdgcn_alignbyte(cur, prev, 3);
+            uint32_t d4 = ((u >> 1) & 0x7F7F7F7Fu) ^ ((u & 0x01010101u) * 255u);
+            if (i >= t.n) d4 = 0;
+            else if (t.n - i < 4) d4 &= 0xFFFFFFFFu >> (8 * (4 - (t.n - i)));
+            if (has_head) d4 &= ~(0xFFu << (8 * hk));
+            const uint32_t p0 = d4 & 255u, p1 = p0 + ((d4 >> 8) & 255u), p2 = p1 + ((d4 >> 16) & 255u), p3 = p2 + (d4 >> 24);
+            const uint32_t incl = wave_scan_incl(p3);
+            const uint32_t pb_ = incl - p3;  // wave-local P in front of this lane's first pixel
+            const uint32_t pbefore = hk == 0 ? 0u : (hk == 1 ? p0 : (hk == 2 ? p1 : p2));  // the lane's deltas in front of its head
+            const uint32_t Hown = (A - (pb_ + pbefore)) & 255u;
+            const uint32_t M = wave_scan_max(has_head ? ((lane + 1u) << 8) | Hown : 0u);
+            const uint32_t Mex = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);  // latest head in the lanes below
+            if (lane == 63) s_wa[par][wv] = (incl & 255u) | ((M & 255u) << 8) | (M ? 1u << 16 : 0u);
+            __syncthreads();
+            uint32_t B = carryP, H = carryH, Cin = 0;
+            for (uint32_t w2 = 0; w2 < NW; w2++) {
+                const uint32_t e = s_wa[par][w2];
+                if (w2 == wv) Cin = B + H;            // no head in this wave before the pixel: P and H both come from outside
+                if (e >> 16) H = ((e >> 8) & 255u) - B;  // (a wave publishes H relative to its own P: B, the P in front of it, cancels inside the wave)
+                B += e & 255u;
+            }
+            carryP = B & 255u; carryH = H & 255u;
+            const uint32_t before = Mex ? Mex & 255u : Cin;  // H for the pixels in front of this lane's own head (or all four)
+            const uint32_t pk[4] = {p0, p1, p2, p3};
+            a4 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t off = (has_head && (uint32_t)k >= hk) ? Hown : before;
+                a4 |= ((pb_ + pk[k] + off) & 255u) << (8 * k);
+            }
+        }
         if (i >= t.n) a4 = 0;
         else if (t.n - i < 4) a4 &= 0xFFFFFFFFu >> (8 * (4 - (t.n - i)));  // pixels past the tile
         if (i == 0) a4 &= 0xFFFFFF00u;                                      // the first pixel is not coded
@@ -1585,8 +1681,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                             uint32_t max_w, uint32_t max_h, int pxsz, const uint8_t *const *d_blob_ptrs, const uint64_t *d_blob_len,
                             uint32_t *d_status, const uint64_t *tile_off, uint32_t t0, uint32_t t1,
                             uint8_t *const *d_raster_ptrs, hipStream_t s, std::string &err, uint64_t *dbg = nullptr,
-                            const uint32_t *d_order = nullptr, uint32_t n_big = 0) {
+                            const uint32_t *d_order = nullptr, uint32_t n_big = 0, uint32_t min_w = 0) {
     const uint32_t cnt = t1 - t0, total = B * cnt, spt = pxsz == 4 ? 10 : 9;
+    // RGBA: the residual kernel rebuilds alpha from its symbols itself (k_dec_resid FOLD) when every tile is at least 4 pixels wide -
+    // every tile of a file the reference can write (RGBA narrower than 4 px is stored at level 7); otherwise k_dec_alpha makes the plane
+    const bool fold = pxsz == 4 && min_w >= 4 && !probe_env("XPNG_NO_ALPHA_FOLD");
     const TileSel sel{t0, cnt, (uint32_t)n_tiles, B, d_order};
     const uint64_t plane = plane_total;
     auto bad = [&](const char *m) { err = m; return 1; };
@@ -1619,7 +1718,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         if (wide && !probe_env("XPNG_NARROW_ALPHA")) { if (!dbg_skip("dec_chain_a")) k_rans2_dec_chain<true, WD_ALPHA_STREAMS, true><<<agroups, 64, DecChainLds<true, WD_ALPHA_STREAMS>::BYTES + pad_ch, ws.side>>>(ws.d_info, total, 9, 1, ws.d_wdec, ws.d_dtab, ws.d_ctxsym, ws.d_asym); }
         else k_rans2_decode<15><<<total, 64, 0, ws.side>>>(ws.d_info, d_tiles, sel, 9, 1, 0, ws.d_ctxsym, ws.d_asym, dbg);
         const size_t pad_al = probe_pad("XPNG_PAD_AL");
-        if (dbg_skip("dec_alpha")) {} else if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
+        if (fold || dbg_skip("dec_alpha")) {} else if (wide) k_dec_alpha<256><<<total, 256, pad_al, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         else k_dec_alpha<1024><<<total, 1024, 0, ws.side>>>(ws.d_info, d_tiles, sel, ws.d_asym, ws.d_alpha);
         if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) return bad("join record failed");
     }
@@ -1639,9 +1738,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // the long walk is the residual / reconstruction work of the few big tiles only.
     const bool band = wide && max_w <= RB_MAXW && !probe_env("XPNG_WAVEFRONT_RECON");
     // (a third stream per context: with fewer hardware queues than the streams of all contexts in flight, streams share a queue
-    // and serialise - measured 31 -> 21 Gpx/s at 4 contexts and 16 queues - so the split is taken only when the process asked
-    // the runtime for at least 24 queues, GPU_MAX_HW_QUEUES, as bench.py does)
-    static const bool many_queues = [] { const char *q = getenv("GPU_MAX_HW_QUEUES"); return q && atoi(q) >= 24; }();
+    // and serialise - measured 31 -> 21 Gpx/s at 4 contexts and 16 queues - so the split is taken only when the CALLER asked
+    // the runtime for at least 24 queues, GPU_MAX_HW_QUEUES, as bench.py does, or asks for the split outright (XPNG_SPLIT).  The
+    // default the library writes into the environment when it is loaded does not count: if HIP was initialised before the load,
+    // the runtime never saw it)
+    static const bool many_queues = user_hw_queues() >= 24;
     const bool split = band && d_order && n_big > 0 && n_big < cnt && !probe_env("XPNG_NARROW_WALK") && !getenv("XPNG_NO_SPLIT") &&
                        (many_queues || getenv("XPNG_SPLIT"));
     const uint32_t jb = split ? n_big * B : 0;
@@ -1668,10 +1769,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
-            if (!dbg_skip("resid_small")) k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
+            if (dbg_skip("resid_small")) {} else if (fold) k_dec_resid<4, 256, true><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
+            else k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
             if (!dbg_skip("recon_small")) k_dec_recon_band<4><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb, total);
         } else {
-            k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, jb);
+            k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
             k_dec_recon_band<3><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb, total);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
@@ -1680,14 +1782,16 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4 && hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
     if (pxsz == 4) {
-        if (dbg_skip("resid_big")) {} else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        if (dbg_skip("resid_big")) {} else if (wide && fold) k_dec_resid<4, 256, true><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else if (fold) k_dec_resid<4, 1024, true><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
         if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0, nt);
         else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
-        if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
-        else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_nlseq, ws.d_resid, 0);
+        if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
         if (band) k_dec_recon_band<3><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0, nt);
         else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
         else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);

@@ -165,12 +165,112 @@ __device__ __forceinline__ void rgb_group_interior(const int useGrad, const int 
     }
 }
 
+
+// ---- stream lengths without a pass of their own [r4] ----------------------------------------------------------------------------
+// The nine context-stream lengths of a tile are a histogram of its nl plane (k_m1_lens below).  Through round 3 a kernel of its own
+// (k_m1_count) re-read the plane for it: 1 B/px of HBM traffic and a launch on the encode's critical path.  The transform holds every
+// nl it writes, so it counts them itself: a thread keeps packed per-bin counters of its own pixels (NlAcc below), remembers its last
+// group with a coded pixel, and the workgroup adds its nine sums to the tile's
+// counters nlh[tile * NLH_STRIDE + c] and raises nlh[.. + 9] to ((index of its last coded pixel + 1) << 4 | that pixel's nl).
+constexpr uint32_t NLH_STRIDE = 12;  // u32 per tile: nine counts, the last-coded-pixel key, two spare
+#ifndef XPNG_HIST_VARIANT
+#define XPNG_HIST_VARIANT 1
+#endif
+#if XPNG_HIST_VARIANT == 0
+// one 64-bit accumulator of nine 6-bit fields (a thread sees at most 24 pixels of a strip; the marker NL_NONE = 255 lands at bit
+// (6 * 255) & 63 = 58, above the nine fields, and whatever it carries out of bit 63 is gone)
+struct NlAcc { uint64_t acc; uint32_t last_onl, last_i0; };
+__device__ __forceinline__ NlAcc nlacc_zero() { return NlAcc{0ull, 0xFFFFFFFFu, 0u}; }
+// onl = the nl bytes of four consecutive pixels (NL_NONE: not coded), i0 = index of the first of them inside the tile
+__device__ __forceinline__ void nlacc_add(NlAcc &a, uint32_t onl, uint32_t i0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.acc += 1ull << ((6u * ((onl >> (8 * k)) & 255u)) & 63u);
+    const bool any = onl != 0xFFFFFFFFu;
+    a.last_onl = any ? onl : a.last_onl;  // (a thread's groups come in increasing pixel order: the last assignment wins)
+    a.last_i0 = any ? i0 : a.last_i0;
+}
+__device__ __forceinline__ void nlacc_fields(const NlAcc &a, uint32_t *f) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) f[c] = (uint32_t)(a.acc >> (6 * c)) & 63u;
+}
+#else
+// four 32-bit accumulators, one per pixel position of a group, each of nine 3-bit fields: a thread sees at most six groups of a
+// strip (seven would still fit), so a field counts to 6; one pixel is a multiply-by-3, a shift and an add.  The marker NL_NONE = 255
+// lands at bit (3 * 255) & 31 = 29, above the nine fields (bits 0..26), and whatever it carries out of bit 31 is gone.
+struct NlAcc { uint32_t acc[4]; uint32_t last_onl, last_i0; };
+__device__ __forceinline__ NlAcc nlacc_zero() { return NlAcc{{0u, 0u, 0u, 0u}, 0xFFFFFFFFu, 0u}; }
+// onl = the nl bytes of four consecutive pixels (NL_NONE: not coded), i0 = index of the first of them inside the tile
+__device__ __forceinline__ void nlacc_add(NlAcc &a, uint32_t onl, uint32_t i0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.acc[k] += 1u << ((3u * ((onl >> (8 * k)) & 255u)) & 31u);
+    const bool any = onl != 0xFFFFFFFFu;
+    a.last_onl = any ? onl : a.last_onl;  // (a thread's groups come in increasing pixel order: the last assignment wins)
+    a.last_i0 = any ? i0 : a.last_i0;
+}
+__device__ __forceinline__ void nlacc_fields(const NlAcc &a, uint32_t *f) {
+    // even fields (bins 0, 2, 4, 6, 8) and odd fields (1, 3, 5, 7) apart, so that the four accumulators add up in 6-bit fields
+    uint32_t ev = 0, od = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { ev += a.acc[k] & 0x71C71C7u; od += (a.acc[k] >> 3) & 0x1C71C7u; }
+#pragma unroll
+    for (int c = 0; c < 9; c++) f[c] = (((c & 1) ? od : ev) >> (6 * (c >> 1))) & 63u;
+}
+#endif
+// the workgroup's sums -> the tile's counters.  Every thread of the THREADS-thread workgroup calls it once (it holds a barrier);
+// s_red: THREADS / 64 x 6 words of LDS nobody else uses.
+template <int THREADS>
+__device__ __forceinline__ void nlacc_commit(const NlAcc &a, uint32_t (*s_red)[6], uint32_t *__restrict__ nlh_tile) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t f[9];
+    nlacc_fields(a, f);
+    // two 16-bit fields per word: a workgroup sees at most 5376 pixels
+    uint32_t w[5] = {f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16), f[8]};
+    uint32_t key = 0;
+    if (a.last_onl != 0xFFFFFFFFu) {
+        const uint32_t kb = (31u - (uint32_t)__clz((int)~a.last_onl)) >> 3;  // highest byte that is not NL_NONE (its complement is not 0)
+        key = ((a.last_i0 + kb + 1u) << 4) | ((a.last_onl >> (8 * kb)) & 15u);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) w[q] = wave_scan_incl(w[q]);
+    key = wave_scan_max(key);
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) s_red[wv][q] = w[q];
+        s_red[wv][5] = key;
+    }
+    __syncthreads();
+    if (tid < 10) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < THREADS / 64; w2++) {
+            const uint32_t x = s_red[w2][tid < 9 ? tid >> 1 : 5];
+            if (tid < 9) v += (tid & 1) ? x >> 16 : x & 0xFFFFu;
+            else v = x > v ? x : v;
+        }
+        if (v) { if (tid < 9) atomicAdd(nlh_tile + tid, v); else atomicMax(nlh_tile + 9, v); }
+    }
+}
+// counters -> the nine stream lengths (common.hpp: stream-scratch layout): stream c receives the nl of every coded pixel whose
+// predecessor (the previous coded pixel; the first one's is 0, libxpng.c:497-508) has nl = c:
+//     len[c] = hist[c] - [c == nl of the last coded pixel] + [c == 0]            (all zero when the tile codes no pixel)
+__global__ __launch_bounds__(256) void k_m1_lens(const uint32_t *__restrict__ nlh, TileSel sel, uint32_t total, uint32_t *__restrict__ ctx_n) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total * 9) return;
+    const uint32_t tile = vtile(sel, j / 9), c = j % 9;
+    const uint32_t l = nlh[(uint64_t)tile * NLH_STRIDE + 9];
+    uint32_t len = nlh[(uint64_t)tile * NLH_STRIDE + c];
+    if (l) len = len - ((l & 15u) == c ? 1u : 0u) + (c == 0 ? 1u : 0u);
+    ctx_n[(uint64_t)tile * 9 + c] = len;
+}
+
 constexpr uint32_t TG_REPS = 4;  // 1024-pixel chunks per workgroup of k_m1_transform_generic
 template <int PXSZ>
 __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                               const TileDesc *__restrict__ tiles, TileSel sel,
                                                               uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
-                                                              uint8_t *__restrict__ planes, uint64_t plane_stride) {
+                                                              uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t *__restrict__ nlh) {
+    __shared__ uint32_t s_red[4][6];
+    NlAcc hacc = nlacc_zero();
     const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
     const TileDesc t = tiles[tile];
     const uint8_t *__restrict__ raster = rasters[t.img];
@@ -180,7 +280,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
     const int pr = pr_from_sums(sums + (uint64_t)tile * 4, PXSZ, t.w, t.h);
     for (uint32_t rep = 0; rep < TG_REPS; rep++) {
     const uint32_t i0 = ((chunk * TG_REPS + rep) * 256 + threadIdx.x) * 4;
-    if (i0 >= t.n) return;
+    if (i0 >= t.n) break;
     const int useGrad = (pr >> 1) & 1, useG = pr & 1;
     uint32_t y = i0 / t.w, x = i0 - y * t.w;
     uint32_t onl = 0, orr = 0, og = 0, ob = 0, oa = 0;
@@ -220,10 +320,13 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
     *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
     *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
     if (PXSZ == 4) *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+    nlacc_add(hacc, onl, i0);
     }
+    if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE);  // (nlh is a kernel argument: the whole workgroup takes the same side)
 }
 
 constexpr uint32_t TR_ROWS = 8, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
+static_assert((TR_ROWS * TR_MAXW / 4 + 255) / 256 <= 7 && TG_REPS <= 7, "NlAcc: a thread's groups per workgroup must fit its 3-bit fields");
 // phase 2 of k_m1_transform_rgba, specialised on the tile's predictor flags so that no per-pixel branch on them remains
 // one group of 4 consecutive pixels of a strip staged in LDS (RGBA): the five packed symbol dwords.  g = group index inside the
 // strip, (yy, x0) = row inside the strip and column of its first pixel.
@@ -314,7 +417,7 @@ __device__ __forceinline__ void rgba_group(const int useGrad, const int useG, co
 }
 
 __device__ __forceinline__ void transform_phase2(const int useGrad, const int useG, const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint32_t y0, uint32_t first,
-                                                 uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride) {
+                                                 uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride, NlAcc &hacc) {
     const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
     // (row, column) of a thread's first group by one division, then advanced incrementally: +1024 pixels per iteration
     uint32_t yy = (threadIdx.x * 4) / t.w, x0 = threadIdx.x * 4 - yy * t.w;
@@ -330,6 +433,7 @@ __device__ __forceinline__ void transform_phase2(const int useGrad, const int us
         *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
         *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
         *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
+        nlacc_add(hacc, onl, y0 * t.w + j0);
     }
 }
 
@@ -346,8 +450,10 @@ __device__ __forceinline__ void transform_phase2(const int useGrad, const int us
 __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                            uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
                                                            uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
-                                                           uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks) {
+                                                           uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks,
+                                                           uint32_t *__restrict__ nlh) {
     __shared__ __align__(16) uint8_t rows[(TR_ROWS + 1) * TR_PITCH];
+    __shared__ uint32_t s_red[4][6];
     // Consecutive block ids round-robin over the 8 XCDs, each with its own L2; consecutive strips of a tile share a halo row.
     // The grid is padded to a multiple of 8 and re-read so that each XCD works through a contiguous run of strips.
     const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -398,7 +504,8 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
     }
     __syncthreads();
     // ---- phase 2 (dispatch once per workgroup on the tile's predictor flags)
-    { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) & 3u; transform_phase2((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, nrows, planes, plane_stride); }
+    { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) & 3u; NlAcc hacc = nlacc_zero(); transform_phase2((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, nrows, planes, plane_stride, hacc);
+      if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE); }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -470,7 +577,7 @@ __device__ __forceinline__ void rgb_group(const int useGrad, const int useG, con
 }
 
 __device__ __forceinline__ void transform_phase2_rgb(const int useGrad, const int useG, const uint8_t *rows, const TileDesc &t, uint64_t bpr, uint64_t g0, uint32_t y0, uint32_t first,
-                                                     uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride) {
+                                                     uint32_t nrows, uint8_t *__restrict__ planes, uint64_t plane_stride, NlAcc &hacc) {
     const uint32_t strip_px = nrows * t.w, groups = (strip_px + 3) >> 2;
     uint32_t yy = (threadIdx.x * 4) / t.w, x0 = threadIdx.x * 4 - yy * t.w;
     const uint32_t dy = 1024 / t.w, dx = 1024 - dy * t.w;
@@ -484,14 +591,17 @@ __device__ __forceinline__ void transform_phase2_rgb(const int useGrad, const in
         *reinterpret_cast<uint32_t *>(planes + 1 * plane_stride + o) = orr;
         *reinterpret_cast<uint32_t *>(planes + 2 * plane_stride + o) = og;
         *reinterpret_cast<uint32_t *>(planes + 3 * plane_stride + o) = ob;
+        nlacc_add(hacc, onl, y0 * t.w + j0);
     }
 }
 
 __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                           uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
                                                           uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
-                                                          uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks) {
+                                                          uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks,
+                                                          uint32_t *__restrict__ nlh) {
     __shared__ __align__(16) uint8_t rows[TR3_LDS_PAD + (TR_ROWS + 1) * TR_PITCH + 16];
+    __shared__ uint32_t s_red[4][6];
     const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware: consecutive strips of a tile on one XCD
     if (bid >= nblocks) return;
     const uint32_t tile = vtile(sel, bid / strips_per_tile), strip = bid % strips_per_tile;
@@ -536,78 +646,11 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
         for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
     }
     __syncthreads();
-    { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3) & 3u; transform_phase2_rgb((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, g0, y0, first, nrows, planes, plane_stride); }
+    { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3) & 3u; NlAcc hacc = nlacc_zero(); transform_phase2_rgb((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, g0, y0, first, nrows, planes, plane_stride, hacc);
+      if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE); }
 }
 
 // --------------------------------------------------------------------------------------------------
-// Lengths of the nine context streams of a tile, BEFORE anything is routed (common.hpp: stream-scratch layout).  Stream c gets
-// the nl of every coded pixel whose predecessor (the previous coded pixel; the first one's is 0, libxpng.c:497-508) has nl = c:
-//     len[c] = hist[c] - [c == nl of the last coded pixel] + [c == 0]            (all zero when the tile codes no pixel)
-// with hist = histogram of the nl plane over coded pixels.  One 256-thread workgroup per tile reads the plane once (16 pixels
-// per thread and step; nine 7-bit fields of a 64-bit accumulator, spilled into nine counters every 7 steps).
-// core: histogram of the tile's nl plane over coded pixels -> s_hist[9] (LDS), and s_last = (index of the last coded pixel + 1) << 4 |
-// its nl (0: the tile codes no pixel).  THREADS-thread workgroup (256 for batches, 1024 for a few tiles: the pass sits on a lone
-// image's critical path); both LDS objects are valid after the closing barrier.
-template <int THREADS>
-__device__ __forceinline__ void tile_nl_histogram(const TileDesc &t, const uint8_t *__restrict__ planes, uint32_t *s_hist, uint32_t *s_last) {
-    const uint32_t tid = threadIdx.x;
-    const uint4 *pnl = reinterpret_cast<const uint4 *>(planes + t.pbase);  // (plane bases are multiples of 256; >= 192 bytes of slack behind a tile)
-    if (tid < 9) s_hist[tid] = 0;
-    if (tid == 0) *s_last = 0;
-    __syncthreads();
-    uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
-    uint64_t acc = 0;
-    uint32_t pend = 0;
-    auto spill = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 9; c++) cnt[c] += (uint32_t)(acc >> (7 * c)) & 127u;
-        acc = 0; pend = 0;
-    };
-    for (uint32_t i0 = 16 * tid; i0 < t.n; i0 += 16 * THREADS) {
-        const uint4 v = pnl[i0 >> 4];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t nl = (w[q >> 2] >> (8 * (q & 3))) & 255u, i = i0 + (uint32_t)q;
-            const bool coded = nl != NL_NONE && i < t.n;
-            const uint32_t f = nl < 8u ? nl : 8u;  // (nl <= 8 for coded pixels)
-            acc += coded ? 1ull << (7 * f) : 0ull;
-            last = coded ? ((i + 1) << 4) | f : last;  // (pixels in increasing order: the last assignment wins)
-        }
-        if (++pend == 7) spill();  // 7 x 16 = 112 <= 127 per field
-    }
-    spill();
-#pragma unroll
-    for (int c = 0; c < 9; c++) {
-        uint32_t v = cnt[c];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if ((tid & 63) == 0 && v) atomicAdd(&s_hist[c], v);
-    }
-    {
-        uint32_t v = last;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
-        if ((tid & 63) == 0 && v) atomicMax(s_last, v);
-    }
-    __syncthreads();
-}
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_m1_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint8_t *__restrict__ planes,
-                                                      uint32_t *__restrict__ ctx_n) {
-    const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
-    const TileDesc t = tiles[tile];
-    __shared__ uint32_t s_hist[9];
-    __shared__ uint32_t s_last;
-    tile_nl_histogram<THREADS>(t, planes, s_hist, &s_last);
-    if (tid < 9) {
-        const uint32_t l = s_last;
-        uint32_t len = s_hist[tid];
-        if (l) len = len - ((l & 15u) == tid ? 1u : 0u) + (tid == 0 ? 1u : 0u);
-        ctx_n[(uint64_t)tile * 9 + tid] = len;
-    }
-}
-
 // --------------------------------------------------------------------------------------------------
 // K3  stream formation.  One 1024-thread workgroup walks one tile in raster order, 1024 pixels per step.
 // Three serial couplings of the reference loop become wave-level prefix operations:
@@ -615,7 +658,7 @@ __global__ __launch_bounds__(THREADS) void k_m1_count(const TileDesc *__restrict
 //   (ii) append position inside context stream cx[pl]   -> one ballot/popcount per context (9)
 //   (iii) bit cursor of k (3*nl bits per coded pixel)   -> wave inclusive scan + cross-wave offsets,
 //        bits are OR-ed MSB-first into an LDS word window and spliced into k with a carried partial word.
-// Outputs: ctx streams (their lengths and places are known beforehand: k_m1_count), k words + count.   grid = tiles, block = 1024.
+// Outputs: ctx streams (their lengths and places are known beforehand: k_m1_lens), k words + count.   grid = tiles, block = 1024.
 // THREADS = 1024 for a few tiles (shortest serial walk per tile); 256 for large batches: the chain kernels of other
 // batches in flight leave few CUs with room for a 16-wave workgroup, but almost all have room for a 4-wave one.
 template <int PXSZ, int ST_THREADS>

@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void k_m2_classify(const uint8_t *const *__res
 
 // --------------------------------------------------------------------------------------------------
 // stream lengths of every tile, before anything is routed (the layout above needs them): a colour tile's nine context streams as
-// in k_m1_count, its class stream v holds one symbol (v = 1, 2) or three (v >= 3) per coded pixel with nl = v; a gray tile's four
-// candidate streams hold n - 1 symbols each; everything else 0.   grid = tiles, block = 256.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_m2_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
-                                                  const uint8_t *__restrict__ planes, uint32_t *__restrict__ stream_n) {
+// in k_m1_lens, its class stream v holds one symbol (v = 1, 2) or three (v >= 3) per coded pixel with nl = v; a gray tile's four
+// candidate streams hold n - 1 symbols each; everything else 0.  The histogram of the nl plane comes from the transform itself
+// (nlh, m1_encode.hpp [r4]: rounds 2-3 re-read the plane here).   grid = tiles, block = 64.
+__global__ __launch_bounds__(64) void k_m2_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
+                                                 const uint32_t *__restrict__ nlh, uint32_t *__restrict__ stream_n) {
     const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
     const TileDesc t = tiles[tile];
     const uint32_t f = flags[tile];
@@ -111,15 +111,13 @@ __global__ __launch_bounds__(THREADS) void k_m2_count(const TileDesc *__restrict
         if (tid < M2_SLOTS) sn[tid] = gray && tid >= 17 ? t.n - 1 : 0u;
         return;
     }
-    __shared__ uint32_t s_hist[9];
-    __shared__ uint32_t s_last;
-    tile_nl_histogram<THREADS>(t, planes, s_hist, &s_last);
+    const uint32_t *h = nlh + (uint64_t)tile * NLH_STRIDE;
     if (tid < 9) {
-        const uint32_t l = s_last;
-        uint32_t len = s_hist[tid];
+        const uint32_t l = h[9];
+        uint32_t len = h[tid];
         if (l) len = len - ((l & 15u) == tid ? 1u : 0u) + (tid == 0 ? 1u : 0u);
         sn[tid] = len;
-        if (tid >= 1) sn[8 + tid] = s_hist[tid] * (tid >= 3 ? 3u : 1u);
+        if (tid >= 1) sn[8 + tid] = h[tid] * (tid >= 3 ? 3u : 1u);
     }
     if (tid >= 17 && tid < M2_SLOTS) sn[tid] = 0;
 }

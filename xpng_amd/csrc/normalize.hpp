@@ -9,12 +9,16 @@
 
 namespace xpng {
 
-// flags[0] |= hidden, flags[1] |= translucent.  One uint4 (4 pixels) per thread per iteration.
+// flags[0] |= hidden, flags[1] |= translucent.  One uint4 (4 pixels) per thread per iteration; px needs only its natural 4-byte
+// alignment (a band of a raster starts at any pixel): the pixels in front of the first 16-byte boundary and behind the last whole
+// group are looked at one by one.
 __global__ __launch_bounds__(256) void k_norm_flags(const uint32_t *__restrict__ px, uint64_t n, uint32_t *__restrict__ flags) {
     uint32_t hidden = 0, transl = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, n4 = n / 4;
+    const uint64_t head = min(n, (uint64_t)(((16u - (uint32_t)((uintptr_t)px & 15u)) & 15u) >> 2));
+    const uint32_t *body = px + head;
+    const uint64_t nb = n - head, stride = (uint64_t)gridDim.x * blockDim.x, n4 = nb / 4;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const uint4 v = reinterpret_cast<const uint4 *>(px)[i];
+        const uint4 v = reinterpret_cast<const uint4 *>(body)[i];
         const uint32_t p[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -23,13 +27,29 @@ __global__ __launch_bounds__(256) void k_norm_flags(const uint32_t *__restrict__
             transl |= a != 255 ? 1u : 0u;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail pixels
-        const uint32_t v = px[n4 * 4 + threadIdx.x], a = v >> 24;
-        hidden |= (a == 0 && (v & 0xFFFFFFu)) ? 1u : 0u;
-        transl |= a != 255 ? 1u : 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 8) {  // head pixels (threads 0..2) and tail pixels (threads 4..6)
+        const uint32_t t = threadIdx.x & 3u;
+        const bool tail = threadIdx.x >= 4;
+        if (t < (tail ? (nb & 3) : head)) {
+            const uint32_t v = tail ? body[n4 * 4 + t] : px[t], a = v >> 24;
+            hidden |= (a == 0 && (v & 0xFFFFFFu)) ? 1u : 0u;
+            transl |= a != 255 ? 1u : 0u;
+        }
     }
     if (__ballot(hidden) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1u);
     if (__ballot(transl) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1u);
+}
+
+// the rewrite of the "hidden" case IN PLACE on a raster this library owns, and only when flags[0] says there is something to
+// rewrite (the kernel is launched behind k_norm_flags on the same stream without the host looking at the flag in between): pixels
+// with alpha 0 become 0 (libxpng.c:699-707), everything else is left alone - nothing is written for a pixel that does not change
+__global__ __launch_bounds__(256) void k_norm_zero_hidden_if(const uint32_t *__restrict__ flags, uint32_t *__restrict__ px, uint64_t n) {
+    if (!flags[0]) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = px[i];
+        if ((v >> 24) == 0 && v) px[i] = 0u;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_norm_zero_hidden(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {

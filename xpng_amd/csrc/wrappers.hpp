@@ -108,6 +108,21 @@ static void ctx_checkin(xpnghip_ctx *c) {
     }
     for (xpnghip_ctx *v : victims) xpnghip_ctx_destroy(v);
 }
+// Nothing of the call that held a context may still be running when the context goes back to the pool: an early error exit (a
+// failed launch or allocation for shard k > 0, a corrupt blob) leaves kernels and copies of the earlier shards in flight - copies
+// that read or write the CALLER's buffers, which the caller may free as soon as the call has returned, and workspaces the next
+// thread to check this context out would drive from another stream with nothing ordering the two.  On the success
+// paths these streams are idle already and the synchronisations return at once.
+static void ctx_quiesce(xpnghip_ctx *c) {
+    if (!c) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(c->device) == hipSuccess) {
+        hipStream_t qs[4] = {c->stream, c->enc_side, c->dec.side, c->dec.side2};
+        for (hipStream_t q : qs) if (q) (void)hipStreamSynchronize(q);
+    }
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+}
 struct CtxLease {  // a context for the duration of one call
     xpnghip_ctx *c = nullptr;
     CtxLease() = default;
@@ -115,7 +130,7 @@ struct CtxLease {  // a context for the duration of one call
     CtxLease(const CtxLease &) = delete;
     CtxLease &operator=(const CtxLease &) = delete;
     CtxLease(CtxLease &&o) noexcept : c(o.c) { o.c = nullptr; }
-    ~CtxLease() { ctx_checkin(c); }
+    ~CtxLease() { ctx_quiesce(c); ctx_checkin(c); }
 };
 
 static int ensure_buf(uint8_t *&p, uint64_t &cap, uint64_t need) {
@@ -257,10 +272,11 @@ static int check_geometry(uint64_t w, uint64_t h, int pxsz) {
     return 0;
 }
 
-// Touches the caller's (typically freshly malloc()ed) raster, one write per page, on a few helper threads while the kernels
-// run: its first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.  The
-// raster is the call's output buffer - its contents are undefined until the call returns 0 - so writing zeros early is
-// harmless; if a helper thread cannot be created the pages simply fault during the copy.
+// Touches the caller's (typically freshly malloc()ed) raster, one access per page, on a few helper threads while the kernels
+// run: its first-touch page faults (16 k of them for a 4096^2 RGBA raster: ~4 ms) otherwise land inside the download.  A page is
+// faulted in by writing back the byte that was read from it: the contents do not change, so a file that is rejected later leaves
+// the caller's buffer as it was, at every raster size (the decode contract: a rejected tile's pixels stay untouched).
+// If a helper thread cannot be created the pages simply fault during the copy.
 struct Prefault {
     static constexpr int NT = 4;
     std::thread th[NT];
@@ -269,7 +285,7 @@ struct Prefault {
         const uint64_t part = ((s / NT) + 4095) & ~4095ull;
         for (int t = 0; t < NT; t++) {
             const uint64_t a = std::min<uint64_t>(s, t * part), b = std::min<uint64_t>(s, (t + 1) * part);
-            try { th[t] = std::thread([=] { for (uint64_t o = a; o < b; o += 4096) raster[o] = 0; }); }
+            try { th[t] = std::thread([=] { volatile uint8_t *p = raster; for (uint64_t o = a; o < b; o += 4096) { const uint8_t v = p[o]; p[o] = v; } }); }
             catch (...) { return; }  // (std::system_error: no more threads - the ones already started are joined below)
             started = t + 1;
         }
@@ -572,26 +588,50 @@ extern "C" int xpnghip_normalize_device(const void *d_rgba, uint64_t npx, void *
 }
 
 // ---- staged image ------------------------------------------------------------------------------------------------
-// One object per xpng_store call in flight (include/xpng_hip.h): upload buffer, rewrite buffer, flag block and a stream of its
+// One object per xpng_store call in flight (include/xpng_hip.h): upload buffer, rewrite buffer, flag block and streams of its
 // own.  Idle objects are pooled with their buffers.
+//
+// Band pipeline [r4] (one device, an ordinary image: the geometry pipeline_shards accepts).  Through round 3 xpng_store uploaded the
+// WHOLE raster, normalised it, read the two flags back and only then started ONE unsplit encode: the tile-row overlap that took
+// xpnghip_encode_tiles from 13.7 to 12.1 ms never ran for the call the boundary replaces.  Now the
+// raster moves in the same three tile-row bands, each on a stream of its own: upload -> k_norm_flags -> k_norm_zero_hidden_if (in
+// place) -> the band's tile encode.  What makes that legal is the shape of normalize_RGBA (libxpng.c:688-721): the rewrite of
+// hidden colours is per pixel, so a band can apply it from its own flag; the only whole-image question is "RGBA or RGB", and RGB
+// needs NO pixel with alpha != 255 anywhere (a hidden pixel has alpha 0, so it is translucent too) - the first band that holds a
+// translucent pixel settles it, and for an image with real alpha that is the first band, 13 % of the raster.  xpnghip_image_begin
+// returns as soon as it is settled; the remaining bands are uploaded by whoever needs them next (the encode, band by band; a fetch
+// or the single-colour test, all at once), which is why the caller's raster must stay valid until xpnghip_image_end.  An opaque
+// RGBA raster is uploaded whole and repacked to RGB as before.
+struct ImgBand { uint32_t y0, y1; bool issued; };
 struct xpnghip_image {
     int dev = 0;
     uint64_t w = 0, h = 0, cap_in = 0, cap_norm = 0;
-    int pxsz = 0;
-    uint8_t *d_in = nullptr, *d_norm = nullptr;  // uploaded raster; rewritten raster (when normalisation changed it)
+    int pxsz = 0, pxsz_in = 0;
+    uint8_t *d_in = nullptr, *d_norm = nullptr;  // uploaded raster (hidden colours zeroed in place); repacked RGB raster
     const uint8_t *cur = nullptr;                // the staged (normalised) raster
-    uint32_t *flags = nullptr;
+    uint32_t *flags = nullptr;                   // device: [0..1] whole-image normalisation flags, [2] single colour, [4 + 2k ..] band k
+    uint32_t *h_flags = nullptr;                 // pinned: band k's two flags at [2k]
     hipStream_t stream = nullptr;
+    const uint8_t *h_src = nullptr;              // the caller's raster, while bands may still have to be uploaded
+    std::vector<ImgBand> bands;                  // empty: whole-image form (everything is on `stream`)
+    hipStream_t bs[3] = {nullptr, nullptr, nullptr};
 };
 static std::vector<xpnghip_image *> g_idle_images;  // guarded by g_pool_mu
 constexpr size_t IMAGE_POOL_MAX = 4;
+static void image_quiesce(xpnghip_image *im) {
+    for (hipStream_t q : im->bs) if (q) (void)hipStreamSynchronize(q);
+    if (im->stream) (void)hipStreamSynchronize(im->stream);
+}
 static void image_destroy(xpnghip_image *im) {
     if (!im) return;
     (void)hipSetDevice(im->dev);
-    if (im->stream) { (void)hipStreamSynchronize(im->stream); (void)hipStreamDestroy(im->stream); }
+    image_quiesce(im);
+    for (hipStream_t q : im->bs) if (q) (void)hipStreamDestroy(q);
+    if (im->stream) (void)hipStreamDestroy(im->stream);
     if (im->d_in) (void)hipFree(im->d_in);
     if (im->d_norm) (void)hipFree(im->d_norm);
     if (im->flags) (void)hipFree(im->flags);
+    if (im->h_flags) (void)hipHostFree(im->h_flags);
     delete im;
 }
 static xpnghip_image *image_checkout(int dev) {
@@ -602,17 +642,47 @@ static xpnghip_image *image_checkout(int dev) {
     }
     xpnghip_image *im = new xpnghip_image();
     im->dev = dev;
-    if (hipStreamCreateWithFlags(&im->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&im->flags, 16) != hipSuccess) { image_destroy(im); return nullptr; }
+    if (hipStreamCreateWithFlags(&im->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&im->flags, 64) != hipSuccess ||
+        hipHostMalloc((void **)&im->h_flags, 64) != hipSuccess) { image_destroy(im); return nullptr; }
     return im;
 }
 static void image_checkin(xpnghip_image *im) {
     xpnghip_image *victim = nullptr;
+    im->bands.clear(); im->h_src = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         g_idle_images.insert(g_idle_images.begin(), im);
         if (g_idle_images.size() > IMAGE_POOL_MAX) { victim = g_idle_images.back(); g_idle_images.pop_back(); }
     }
     image_destroy(victim);
+}
+
+// band k of the caller's raster -> d_in on the band's stream, with its share of normalize_RGBA behind it (launches only)
+static int image_issue_band(xpnghip_image *im, size_t k) {
+    ImgBand &b = im->bands[k];
+    if (b.issued) return 0;
+    const uint64_t bpr = im->w * (uint64_t)im->pxsz_in, off = (uint64_t)b.y0 * bpr, bytes = (uint64_t)(b.y1 - b.y0) * bpr;
+    hipStream_t q = im->bs[k];
+    HIPCHK(hipMemcpyAsync(im->d_in + off, im->h_src + off, bytes, hipMemcpyHostToDevice, q));
+    if (im->pxsz_in == 4) {
+        uint32_t *f = im->flags + 4 + 2 * k;
+        const uint64_t npx = bytes / 4;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((npx / 4 + 255) / 256 + 1, 256 * 16);
+        HIPCHK(hipMemsetAsync(f, 0, 8, q));
+        k_norm_flags<<<blocks, 256, 0, q>>>((const uint32_t *)(im->d_in + off), npx, f);
+        k_norm_zero_hidden_if<<<blocks, 256, 0, q>>>(f, (uint32_t *)(im->d_in + off), npx);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(im->h_flags + 2 * k, f, 8, hipMemcpyDeviceToHost, q));
+    }
+    b.issued = true;
+    return 0;
+}
+// every band uploaded, normalised and finished: the staged raster is complete (whole-raster consumers: fetch, single colour,
+// the multi-device encode, the repack to RGB)
+static int image_complete(xpnghip_image *im) {
+    for (size_t k = 0; k < im->bands.size(); k++) if (image_issue_band(im, k)) return 1;
+    for (size_t k = 0; k < im->bands.size(); k++) HIPCHK(hipStreamSynchronize(im->bs[k]));
+    return 0;
 }
 
 static int image_begin_impl(xpnghip_image **out, const uint8_t *raster, uint64_t w, uint64_t h, int pxsz_in, int *pxsz_out) {
@@ -626,8 +696,32 @@ static int image_begin_impl(xpnghip_image **out, const uint8_t *raster, uint64_t
     auto body = [&]() -> int {
         const uint64_t s = w * h * (uint64_t)pxsz_in;
         if (ensure_buf(im->d_in, im->cap_in, s)) return 1;
+        im->w = w; im->h = h; im->pxsz = im->pxsz_in = pxsz_in; im->cur = im->d_in;
+        im->bands.clear(); im->h_src = raster;
+        std::vector<TileDesc> tiles;
+        std::vector<Shard> sh;
+        if (s >= (24u << 20)) build_tiles(w, h, tiles);
+        if (!tiles.empty() && pipeline_shards(tiles, pxsz_in, s, im->dev, sh) && sh.size() == 3 && !probe_env("XPNG_NO_IMAGE_BANDS")) {
+            for (size_t k = 0; k < 3; k++)
+                if (!im->bs[k]) HIPCHK(hipStreamCreateWithFlags(&im->bs[k], hipStreamNonBlocking));
+            for (const Shard &q : sh) im->bands.push_back(ImgBand{q.y0, q.y1, false});
+            if (pxsz_in == 3) return image_issue_band(im, 0);  // RGB: nothing to decide; the first band's upload starts now
+            if (ensure_buf(im->d_norm, im->cap_norm, s)) return 1;
+            for (size_t k = 0; k < 3; k++) {  // band by band until a translucent pixel settles "stays RGBA"
+                if (image_issue_band(im, k)) return 1;
+                HIPCHK(hipStreamSynchronize(im->bs[k]));
+                if (im->h_flags[2 * k + 1]) return 0;
+            }
+            // no pixel with alpha != 255 anywhere: repack to RGB (libxpng.c:708-718); the whole raster is on the device by now
+            const uint64_t npx = w * h;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((npx / 4 + 255) / 256 + 1, 256 * 16);
+            k_norm_to_rgb<<<blocks, 256, 0, im->stream>>>((const uint32_t *)im->d_in, im->d_norm, npx);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(im->stream));
+            im->cur = im->d_norm; im->pxsz = 3;
+            return 0;
+        }
         HIPCHK(hipMemcpyAsync(im->d_in, raster, s, hipMemcpyHostToDevice, im->stream));
-        im->w = w; im->h = h; im->pxsz = pxsz_in; im->cur = im->d_in;
         if (pxsz_in == 4) {
             if (ensure_buf(im->d_norm, im->cap_norm, s)) return 1;
             int rewritten = 0;
@@ -636,7 +730,7 @@ static int image_begin_impl(xpnghip_image **out, const uint8_t *raster, uint64_t
         }
         return 0;
     };
-    if (body()) { (void)hipStreamSynchronize(im->stream); image_checkin(im); return 1; }
+    if (body()) { image_quiesce(im); image_checkin(im); return 1; }
     *pxsz_out = im->pxsz;
     *out = im;
     return 0;
@@ -649,7 +743,7 @@ extern "C" void xpnghip_image_end(xpnghip_image *im) {
     try {
         DevGuard guard;
         (void)hipSetDevice(im->dev);
-        (void)hipStreamSynchronize(im->stream);
+        image_quiesce(im);  // (nothing of this call may still read the caller's raster or write the staging buffers)
         image_checkin(im);
     } catch (...) {}
 }
@@ -657,6 +751,7 @@ static int image_single_colour_impl(xpnghip_image *im, int *single) {
     if (!im || !single) return fail("no staged image");
     DevGuard guard;
     HIPCHK(hipSetDevice(im->dev));
+    if (image_complete(im)) return 1;
     const uint64_t n = im->w * im->h;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16);
     HIPCHK(hipMemsetAsync(im->flags + 2, 0, 4, im->stream));
@@ -673,11 +768,46 @@ static int image_fetch_impl(xpnghip_image *im, uint8_t *dst) {
     if (!im || !dst) return fail("no staged image");
     DevGuard guard;
     HIPCHK(hipSetDevice(im->dev));
+    if (image_complete(im)) return 1;
     HIPCHK(hipMemcpyAsync(dst, im->cur, im->w * im->h * (uint64_t)im->pxsz, hipMemcpyDeviceToHost, im->stream));
     HIPCHK(hipStreamSynchronize(im->stream));
     return 0;
 }
 extern "C" int xpnghip_image_fetch(xpnghip_image *im, uint8_t *dst) { XPNG_GUARDED(image_fetch_impl(im, dst)) }
+
+// the banded encode: tile-row group k is coded on band k's stream, right behind the band's upload and normalisation
+static int image_encode_banded(xpnghip_image *im, std::vector<Shard> &sh, const std::vector<TileDesc> &tiles, int mode, uint8_t **blobs, uint64_t *blobs_len) {
+    const ApiTrace tr;
+    std::vector<CtxLease> leases;
+    leases.reserve(sh.size());
+    struct Quiesce { xpnghip_image *im; ~Quiesce() { for (hipStream_t q : im->bs) if (q) (void)hipStreamSynchronize(q); } } quiesce{im};  // (runs before the leases hand the contexts back, on every exit)
+    uint64_t whole_bound = 16;
+    for (const TileDesc &t : tiles) whole_bound += (uint64_t)t.n * im->pxsz + 4;
+    for (size_t k = 0; k < sh.size(); k++) {
+        Shard &s = sh[k];
+        if (image_issue_band(im, k)) return 1;
+        if (!(s.c = ctx_checkout(im->dev, im->w, im->h, im->pxsz, s.r0, s.r1))) return 1;
+        leases.emplace_back(s.c);
+        if (ensure_buf(s.c->d_blobs, s.c->cap_blobs, k == 0 ? whole_bound : xpnghip_ctx_blob_bound(s.c, s.r0, s.r1))) return 1;
+        // (kernels address rows absolutely and touch only the rows of their tiles: the staged raster is handed over whole)
+        if (xpnghip_encode_device(s.c, mode, im->cur, s.r0, s.r1, s.c->d_blobs, nullptr, im->bs[k])) return 1;
+        tr.mark("encode launched, band", (int)k);
+    }
+    uint64_t total = 0;
+    for (size_t k = 0; k < sh.size(); k++) {
+        HIPCHK(hipStreamSynchronize(im->bs[k]));
+        sh[k].len = sh[k].c->h_total[0]; sh[k].off = total; total += sh[k].len;
+        tr.mark("encode done, band", (int)k);
+    }
+    for (size_t k = 1; k < sh.size(); k++) HIPCHK(hipMemcpyAsync(sh[0].c->d_blobs + sh[k].off, sh[k].c->d_blobs, sh[k].len, hipMemcpyDeviceToDevice, im->bs[k]));
+    for (size_t k = 1; k < sh.size(); k++) HIPCHK(hipStreamSynchronize(im->bs[k]));
+    uint8_t *out = (uint8_t *)malloc(total ? total : 1);
+    if (!out) return fail("malloc failed");
+    if (hipMemcpyAsync(out, sh[0].c->d_blobs, total, hipMemcpyDeviceToHost, im->bs[0]) != hipSuccess || hipStreamSynchronize(im->bs[0]) != hipSuccess) { free(out); return fail("blob download failed"); }
+    tr.mark("blobs on the host", 0);
+    *blobs = out; *blobs_len = total;
+    return 0;
+}
 static int image_encode_impl(xpnghip_image *im, uint64_t T, int mode, uint8_t **blobs, uint64_t *blobs_len) {
     if (!im || !blobs || !blobs_len) return fail("no staged image");
     DevGuard guard;
@@ -685,10 +815,23 @@ static int image_encode_impl(xpnghip_image *im, uint64_t T, int mode, uint8_t **
     const uint64_t N = tile_count_for(im->w, im->h);
     const int D = devices_for(T, N);
     if (D > 1) {
+        if (image_complete(im)) return 1;
         HIPCHK(hipStreamSynchronize(im->stream));  // (the shards' streams read the staged raster)
         std::vector<TileDesc> tiles;
         build_tiles(im->w, im->h, tiles);
         return encode_multi(make_shards(tiles, D), tiles, mode, nullptr, im->cur, im->w, im->h, im->pxsz, blobs, blobs_len);
+    }
+    if (!im->bands.empty()) {
+        // the tile-row groups of the encode are the bands of the upload whenever the staged pixel format is the uploaded one (the
+        // tile grid depends on w and h only); after a repack to RGB the raster is complete and the groups are cut afresh
+        std::vector<TileDesc> tiles;
+        std::vector<Shard> sh;
+        build_tiles(im->w, im->h, tiles);
+        bool same = pipeline_shards(tiles, im->pxsz, im->w * im->h * (uint64_t)im->pxsz, im->dev, sh) && sh.size() == im->bands.size();
+        if (same && im->pxsz != im->pxsz_in) { if (image_complete(im)) return 1; }
+        for (size_t k = 0; same && k < sh.size(); k++) same = sh[k].y0 == im->bands[k].y0 && sh[k].y1 == im->bands[k].y1;
+        if (same) return image_encode_banded(im, sh, tiles, mode, blobs, blobs_len);
+        if (image_complete(im)) return 1;
     }
     CtxLease lease(ctx_checkout(im->dev, im->w, im->h, im->pxsz));
     xpnghip_ctx *c = lease.c;
@@ -696,7 +839,7 @@ static int image_encode_impl(xpnghip_image *im, uint64_t T, int mode, uint8_t **
     if (ensure_buf(c->d_blobs, c->cap_blobs, xpnghip_ctx_blob_bound(c, 0, N))) return 1;
     uint64_t len = 0;
     // on the image's stream: ordered behind the upload and the normalisation without a device-wide synchronisation
-    if (xpnghip_encode_device(c, mode, im->cur, 0, N, c->d_blobs, &len, im->stream)) return 1;
+    if (xpnghip_encode_device(c, mode, im->cur, 0, N, c->d_blobs, &len, im->stream)) { (void)hipStreamSynchronize(im->stream); return 1; }
     uint8_t *out = (uint8_t *)malloc(len ? len : 1);
     if (!out) return fail("malloc failed");
     if (hipMemcpyAsync(out, c->d_blobs, len, hipMemcpyDeviceToHost, im->stream) != hipSuccess || hipStreamSynchronize(im->stream) != hipSuccess) { free(out); return fail("blob download failed"); }

@@ -53,8 +53,15 @@ static int fail(const std::string &m) { g_err = m; return 1; }
 // default of 4 hardware queues those streams share queues and serialise (measured: 31 -> 21 Gpx/s).  The runtime reads
 // GPU_MAX_HW_QUEUES when it initialises - the first HIP call of the process - so the library asks for 32 when it is LOADED,
 // unless the caller has chosen a value.  A process that has already initialised HIP before loading this library keeps what it
-// had (export the variable yourself in that case: INTEGRATION.md).
-__attribute__((constructor)) static void xpnghip_on_load(void) { (void)setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+// had (export the variable yourself in that case: INTEGRATION.md) - which is why nothing in the library may conclude from the
+// variable's value that the queues exist unless the CALLER put it there: g_user_hw_queues is what the caller exported (0 = nothing),
+// taken before the library writes its own default.
+static int g_user_hw_queues = 0;
+__attribute__((constructor)) static void xpnghip_on_load(void) {
+    if (const char *q = getenv("GPU_MAX_HW_QUEUES")) g_user_hw_queues = atoi(q);
+    (void)setenv("GPU_MAX_HW_QUEUES", "32", 0);
+}
+namespace xpng { int user_hw_queues() { return g_user_hw_queues; } }
 
 extern "C" int xpnghip_abi_version(void) { return XPNGHIP_ABI_VERSION; }
 extern "C" const char *xpnghip_last_error(void) { return g_err.c_str(); }
@@ -111,7 +118,7 @@ struct xpnghip_ctx {
     uint64_t plane_img = 0, plane_stride = 0, scratch_img = 0, ws_bytes = 0;
     TileDesc *d_tiles = nullptr;
     uint8_t *d_planes = nullptr, *d_scratch = nullptr;  // d_planes (4 or 5 symbol planes) and d_scratch (level-1 stream scratch = the decode's planes): allocated on first use
-    uint32_t *d_sums = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
+    uint32_t *d_sums = nullptr, *d_nlh = nullptr, *d_ctx_n = nullptr, *d_k_n = nullptr, *d_blk_sz = nullptr, *d_tile_sz = nullptr, *d_tile_hdr = nullptr;
     uint64_t *d_off = nullptr, *d_totals = nullptr, *d_dbg = nullptr;
     uint64_t *d_blob_len = nullptr;       // decode: B blob lengths
     uint32_t *d_status = nullptr;         // decode: bit 0 = some tile failed header validation
@@ -172,7 +179,7 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
+    void *ptrs[] = {c->d_tiles, c->d_planes, c->d_scratch, c->d_sums, c->d_nlh, c->d_ctx_n, c->d_k_n, c->d_blk_sz, c->d_tile_sz,
                     c->d_tile_hdr, c->d_off, c->d_totals, c->d_raster, c->d_blobs, c->d_blob_in, c->d_dbg, (void *)c->d_in_ptrs, (void *)c->d_out_ptrs, (void *)c->d_dec_in_ptrs, (void *)c->d_dec_out_ptrs, (void *)c->d_order,
                     c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -225,6 +232,7 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
     // (the stream scratch - 7.5 B/px for a level-1 encode, 8 B/px as the decode's symbol / residual planes: one buffer of the larger
     //  size - and the symbol planes, 4 or 5 B/px, are allocated by the first call that needs them: ensure_scratch, ensure_planes)
     ALLOC(c->d_sums, VN * 16);
+    ALLOC(c->d_nlh, VN * NLH_STRIDE * 4);  // nl histogram + last coded pixel of every tile, filled by the transform (m1_encode.hpp)
     ALLOC(c->d_ctx_n, VN * 9 * 4);
     ALLOC(c->d_k_n, VN * 4);
     ALLOC(c->d_blk_sz, VN * 10 * 4);
@@ -362,8 +370,9 @@ static int launch_chooser(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t
 }
 
 // chooser + transform (BASELINE config 2).  Launch only; no sync.  d_in_ptrs already holds the raster pointers.
+// hist: the transform also leaves the histogram of the nl plane in d_nlh (the stream lengths of the routing kernels come from it)
 template <int PXSZ>
-static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s, size_t pad = 0) {
+static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t t1, hipStream_t s, size_t pad = 0, bool hist = false) {
     if (ensure_planes(c)) return 1;
     const uint32_t cnt = t1 - t0, total = nimg * cnt;
     // image-major here: these two kernels stream the rasters, and neighbouring workgroups on neighbouring rows of ONE raster
@@ -373,18 +382,23 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     uint32_t max_n = 0;
     for (uint32_t i = t0; i < t1; i++) max_n = c->tiles[i].n > max_n ? c->tiles[i].n : max_n;
     if (launch_chooser<PXSZ>(c, nimg, t0, t1, s, pad)) return 1;
-    XPNG_REQUIRE(c->d_planes);
+    XPNG_REQUIRE(c->d_planes, c->d_nlh);
+    uint32_t *nlh = hist ? c->d_nlh : nullptr;
+    if (hist) {
+        if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_nlh, 0, (uint64_t)nimg * sel.N * NLH_STRIDE * 4, s));
+        else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_nlh + ((uint64_t)b * sel.N + t0) * NLH_STRIDE, 0, (uint64_t)cnt * NLH_STRIDE * 4, s));
+    }
     uint32_t max_w = 0, max_h = 0;
     for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (PXSZ == 4 && max_w <= TR_MAXW && !probe_env("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        if (!dbg_skip("transform")) k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
+        if (!dbg_skip("transform")) k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_, nlh);
     } else if (PXSZ == 3 && max_w <= TR_MAXW && !probe_env("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_);
+        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_, nlh);
     } else {
         const uint32_t bpt = (max_n + 1024 * TG_REPS - 1) / (1024 * TG_REPS);
-        k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride);
+        k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride, nlh);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -396,7 +410,7 @@ extern "C" int xpnghip_m1_transform_device(xpnghip_ctx *c, const void *d_raster,
     hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     void *dummy = c->d_out_ptrs;  // no output buffer in this stage
     if (set_ptrs(c, &d_raster, &dummy, 1, s)) return 1;
-    return c->pxsz == 4 ? launch_transform<4>(c, 1, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, 1, (uint32_t)t0, (uint32_t)t1, s);
+    return c->pxsz == 4 ? launch_transform<4>(c, 1, (uint32_t)t0, (uint32_t)t1, s, 0, true) : launch_transform<3>(c, 1, (uint32_t)t0, (uint32_t)t1, s, 0, true);  // (with the nl histogram: the kernel the encode runs)
 }
 
 extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *const *d_rasters, uint32_t nimg, uint64_t t0, uint64_t t1, void *stream) {
@@ -405,7 +419,7 @@ extern "C" int xpnghip_m1_transform_device_batch(xpnghip_ctx *c, const void *con
     hipStream_t s = stream ? (hipStream_t)stream : ctx_stream(c);
     std::vector<void *> dummy(nimg, (void *)c->d_out_ptrs);  // no output buffers in this stage
     if (set_ptrs(c, d_rasters, dummy.data(), nimg, s)) return 1;
-    return c->pxsz == 4 ? launch_transform<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s) : launch_transform<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s);
+    return c->pxsz == 4 ? launch_transform<4>(c, nimg, (uint32_t)t0, (uint32_t)t1, s, 0, true) : launch_transform<3>(c, nimg, (uint32_t)t0, (uint32_t)t1, s, 0, true);
 }
 
 template <int PXSZ>
@@ -432,7 +446,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     // (A fused transform + routing kernel - no nl / r / g / b planes, 3.7 B/px less HBM traffic - existed through round 3 behind
     //  XPNG_FUSED: one long-lived 28 KB workgroup per tile, 12 % slower in the pipeline every time it was measured, and it cannot
     //  know the stream lengths before it routes.  Removed with the worst-case stream layout; git history has it.)
-    if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr)) return 1;
+    if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr, true)) return 1;
     // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
     // preparation and the chains themselves run on their own stream behind the transform
     if (alpha_side) {
@@ -443,9 +457,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
     }
-    // stream lengths (histogram of the nl plane) -> places of the nine context streams -> routing
-    if (dbg_skip("count")) {} else if (small_wg) k_m1_count<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_planes, c->d_ctx_n);
-    else k_m1_count<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_planes, c->d_ctx_n);
+    // stream lengths (from the histogram of the nl plane the transform took as it wrote it) -> places of the nine context streams -> routing
+    k_m1_lens<<<(total * 9 + 255) / 256, 256, 0, s>>>(c->d_nlh, sel, total, c->d_ctx_n);
     if (dbg_skip("streams")) {} else if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     if (narrow) {
@@ -495,10 +508,9 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     HIPCHK(hipMemsetAsync(c->d_stream_n2, 0, VN * M2_SLOTS * 4, s));
     HIPCHK(hipMemsetAsync(c->d_blk2, 0, VN * M2_SLOTS * sizeof(M2Blk), s));
     k_m2_classify<<<total * 16, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, 16, c->d_flags2);
-    if (launch_transform<3>(c, nimg, t0, t1, s)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes (allocates them on first use)
+    if (launch_transform<3>(c, nimg, t0, t1, s, 0, true)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes (allocates them on first use) + nl histogram
     XPNG_REQUIRE(c->d_planes);
-    if ((uint64_t)total * M2_STREAMS > 2048) k_m2_count<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->d_stream_n2);  // stream lengths -> where every stream goes
-    else k_m2_count<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->d_stream_n2);
+    k_m2_count<<<total, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_nlh, c->d_stream_n2);  // stream lengths -> where every stream goes
     if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_streams<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     else k_m2_streams<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     const uint32_t gbpt = (max_n + 256 * M2_GRAY_REPS - 1) / (256 * M2_GRAY_REPS);
@@ -569,8 +581,8 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
         c->h_blob_len.assign(blobs_len, blobs_len + nimg);
     }
     HIPCHK(hipMemsetAsync(c->d_status, 0, 4, s));
-    uint32_t max_w = 0, max_h = 0;
-    for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
+    uint32_t max_w = 0, max_h = 0, min_w = ~0u;
+    for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; min_w = c->tiles[i].w < min_w ? c->tiles[i].w : min_w; }
     if (ensure_arena(c)) return 1;
     XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles, c->dec.arena);
     if (mode == 2) {
@@ -581,7 +593,7 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     }
     return decode_m1_launch(c->dec, nimg, c->tiles.size(), c->plane_stride, c->d_tiles, c->W, max_w, max_h, c->pxsz, c->d_dec_in_ptrs, c->d_blob_len, c->d_status, tile_off,
                             (uint32_t)t0, (uint32_t)t1, c->d_dec_out_ptrs, s, g_err, c->stamps ? c->d_dbg + c->tiles.size() * c->B * 80 : nullptr,
-                            order_for(c, (uint32_t)t0, (uint32_t)t1), order_for(c, (uint32_t)t0, (uint32_t)t1) ? c->n_big : 0u);
+                            order_for(c, (uint32_t)t0, (uint32_t)t1), order_for(c, (uint32_t)t0, (uint32_t)t1) ? c->n_big : 0u, min_w);
 }
 extern "C" int xpnghip_decode_device(xpnghip_ctx *c, int mode, const void *d_blobs, uint64_t blobs_len,
                                      const uint64_t *tile_off, uint64_t t0, uint64_t t1, void *d_raster, void *stream) {
