@@ -31,6 +31,17 @@ inline size_t probe_pad(const char *name) { const char *v = probe_env(name); ret
 // outside probe builds.
 inline hipError_t chain_stream_create(hipStream_t *s) {
     int lo = 0, hi = 0;
+    // (probe builds) XPNG_SIDE_CUMASK=K: the side streams of a context - alpha encode chains, alpha decode chains, the small-tile decode
+    // tail - may use only the first K compute units of the runtime's numbering (the driver deals a queue's mask bits round-robin over
+    // the shader engines and XCDs: K / 8 per XCD); the caller's stream keeps all of them.  VERDICT r3 item 1a: a CU partition.
+    if (const char *m = probe_env("XPNG_SIDE_CUMASK")) {
+        const int k = atoi(m);
+        if (k > 0 && k < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < k; i++) mask[i >> 5] |= 1u << (i & 31);
+            return hipExtStreamCreateWithCUMask(s, 8, mask);
+        }
+    }
     if (probe_env("XPNG_STREAM_PRIORITY")) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, probe_env("XPNG_STREAM_PRIORITY") ? hi : 0);
 }
@@ -56,6 +67,25 @@ __device__ uint32_t g_probe_cap = 0, g_probe_n = 0;
 #else
 #define XPNG_PROBE_BEGIN()
 #define XPNG_PROBE_END(kid)
+#endif
+
+// VALU burner (probe builds only): XPNG_BURN_TR=k / XPNG_BURN_ST=k make every thread of the transform / routing kernels issue 4 k
+// extra full-rate vector instructions per workgroup / per iteration.  Is the pipelined step bound by vector instruction issue?  If
+// it is, `value` falls in proportion to the instructions added (profiles/r04_burn.txt).
+#ifdef XPNG_PROBES
+__device__ uint32_t g_burn_tr = 0, g_burn_st = 0;
+__device__ __forceinline__ void probe_burn(uint32_t k, uint32_t seed, uint32_t *sink) {
+    if (!k) return;
+    uint32_t x = seed;
+    for (uint32_t i = 0; i < k; i++) {
+        x = (x ^ (x << 3)) + i;   // v_lshlrev + v_xor (or one v_lshl_xor?) + v_add: dependent, full rate
+        x = (x ^ (x >> 5)) + seed;
+    }
+    if (x == 0x5A17C0DEu) *sink = x;  // (never, in practice: keeps the loop alive)
+}
+#define XPNG_BURN(var, seed, sink) probe_burn(var, seed, sink)
+#else
+#define XPNG_BURN(var, seed, sink)
 #endif
 
 // Knock-out switch for timing studies (tools/knockout.py; probe builds only): XPNG_SKIP=name,name,... leaves the named kernels

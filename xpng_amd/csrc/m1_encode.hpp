@@ -505,6 +505,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
     __syncthreads();
     // ---- phase 2 (dispatch once per workgroup on the tile's predictor flags)
     { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) & 3u; NlAcc hacc = nlacc_zero(); transform_phase2((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, nrows, planes, plane_stride, hacc);
+      XPNG_BURN(g_burn_tr, threadIdx.x + pr_, reinterpret_cast<uint32_t *>(planes));
       if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE); }
 }
 

@@ -375,6 +375,16 @@ static int encode_multi(std::vector<Shard> sh, const std::vector<TileDesc> &tile
     //  i.e. for the calls other host threads have in flight)
     if (hipMemcpyAsync(out, sh[0].c->d_blobs, total, hipMemcpyDeviceToHost, ctx_stream(sh[0].c)) != hipSuccess || hipStreamSynchronize(ctx_stream(sh[0].c)) != hipSuccess) { free(out); return fail("blob download failed"); }
     tr.mark("blobs on the host", 0);
+    if (sh.back().dev != dev0) {
+        // More than one REAL device: this path (peer copies into device 0's gather buffer) has been rehearsed with fake devices and
+        // gloo ranks but has not yet run on real peers under this library's test-suite (tests/test_gpu_parity.py
+        // test_two_real_devices_code_the_same_bytes skips on one-GPU boxes).  So the gathered bytes are checked before they are
+        // handed out - the size words of the N tiles must walk exactly to the total (libxpng.c:764-769, 982) - and the call says so.
+        uint64_t o = 0;
+        for (size_t i = 0; i < tiles.size() && o + 4 <= total; i++) { uint32_t h0; memcpy(&h0, out + o, 4); const uint32_t sz = h0 & 0xFFFFFFu; if (!sz) { o = ~0ull; break; } o += sz; }
+        if (o != total) { free(out); return fail("multi-device gather: the tile sizes do not walk to the gathered length (peer copies misplaced?)"); }
+        if (g_err.rfind("note:", 0) != 0) g_err = "note: coded on " + std::to_string(sh.size()) + " devices; this multi-device form is opt-in (T > 1) and awaits a byte-parity run on real peer GPUs";
+    }
     *blobs = out; *blobs_len = total;
     return 0;
 }

@@ -264,6 +264,13 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         for (uint32_t i : ord) if ((uint64_t)c->tiles[i].n * 4 >= (uint64_t)c->tiles[ord[0]].n * 3) c->n_big++;
     }
     c->stamps = c->d_dbg && probe_env("XPNG_STAMPS") != nullptr;  // (probe builds only)
+#ifdef XPNG_PROBES
+    {   // VALU burner (common.hpp)
+        const uint32_t btr = (uint32_t)probe_pad("XPNG_BURN_TR"), bst = (uint32_t)probe_pad("XPNG_BURN_ST");
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_burn_tr), &btr, 4);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_burn_st), &bst, 4);
+    }
+#endif
     // (c->stream is created on first use, ctx_stream(): a caller that always passes its own stream never needs it, and every
     //  stream alive takes one of the runtime's hardware queues - with more streams than queues, streams share queues and serialise)
     if (hipHostMalloc((void **)&c->h_total, (uint64_t)batch * 8 + 64) != hipSuccess ||
