@@ -1460,9 +1460,9 @@ __device__ __forceinline__ void recon_band_core(const TileDesc &t, uint8_t *__re
                 if (!grad) pred = __builtin_amdgcn_lerp(prev, nU, 0x01010101u);  // per byte (L + U + 1) >> 1
                 else {
                     const uint32_t Le = prev & 0x00FF00FFu, Ue = nU & 0x00FF00FFu, ULe = nUL & 0x00FF00FFu;
-                    const uint32_t pe = (((Le + Ue) * 3u + 0x04020402u - 2u * ULe) >> 2) & 0x00FF00FFu;
+                    const uint32_t pe = ((times3(Le + Ue) + 0x04020402u - 2u * ULe) >> 2) & 0x00FF00FFu;
                     const int lg = (int)((prev >> 8) & 255u), ug = (int)((nU >> 8) & 255u), ulg = (int)((nUL >> 8) & 255u);
-                    pred = pe | (((uint32_t)(((lg + ug) * 3 - 2 * ulg + 2) >> 2) & 255u) << 8);
+                    pred = pe | (((uint32_t)(((int)times3((uint32_t)(lg + ug)) - 2 * ulg + 2) >> 2) & 255u) << 8);
                 }
                 pred = predmode == 2 ? prev : pred;
                 pred = predmode == 3 ? nU : pred;

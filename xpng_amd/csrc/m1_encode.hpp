@@ -133,10 +133,10 @@ __device__ __forceinline__ uint32_t m1_pixel_interior(const int useGrad, const i
         // every lane positive (range -508 .. 1532) and, being a multiple of 4 * 256, leaves the low 8 bits of the shifted
         // value unchanged; g alone in a 32-bit register with a plain arithmetic shift.
         const uint32_t Le = L & 0x00FF00FFu, Ue = U & 0x00FF00FFu, ULe = UL & 0x00FF00FFu;
-        const uint32_t te = (Le + Ue) * 3u + 0x04020402u - 2u * ULe;
+        const uint32_t te = times3(Le + Ue) + 0x04020402u - 2u * ULe;
         const uint32_t pe = (te >> 2) & 0x00FF00FFu;
         const int lg = (int)((L >> 8) & 255u), ug = (int)((U >> 8) & 255u), ulg = (int)((UL >> 8) & 255u);
-        const uint32_t pg = (uint32_t)(((lg + ug) * 3 - 2 * ulg + 2) >> 2) & 255u;
+        const uint32_t pg = (uint32_t)(((int)times3((uint32_t)(lg + ug)) - 2 * ulg + 2) >> 2) & 255u;
         pred = pe | (pg << 8);
     }
     pred = (pred & 0x00FFFFFFu) | (L & 0xFF000000u);  // alpha always predicts from the left (libxpng.c:511)
@@ -202,7 +202,7 @@ __device__ __forceinline__ NlAcc nlacc_zero() { return NlAcc{{0u, 0u, 0u, 0u}, 0
 // onl = the nl bytes of four consecutive pixels (NL_NONE: not coded), i0 = index of the first of them inside the tile
 __device__ __forceinline__ void nlacc_add(NlAcc &a, uint32_t onl, uint32_t i0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) a.acc[k] += 1u << ((3u * ((onl >> (8 * k)) & 255u)) & 31u);
+    for (int k = 0; k < 4; k++) a.acc[k] += 1u << (__umul24((onl >> (8 * k)) & 255u, 3u) & 31u);
     const bool any = onl != 0xFFFFFFFFu;
     a.last_onl = any ? onl : a.last_onl;  // (a thread's groups come in increasing pixel order: the last assignment wins)
     a.last_i0 = any ? i0 : a.last_i0;
@@ -469,38 +469,42 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
     {
         const uint64_t g0 = (uint64_t)(t.y + first) * bpr + (uint64_t)t.x * 4;  // first staged byte
         const uint32_t row_bytes = t.w * 4;
-        const uint32_t chunks = (uint32_t)(((g0 & 15) + row_bytes + 15) >> 4) + ((bpr & 15) ? 1 : 0);  // per row, upper bound
-        // All of a thread's loads are issued before the first LDS store: ~8 x 16 B in flight per thread (Little's law:
+        const uint32_t chunks = (uint32_t)(((g0 & 15) + row_bytes + 15) >> 4) + ((bpr & 15) ? 1 : 0);  // per row, upper bound (<= 170)
+        // All of a thread's loads are issued before the first LDS store: ~5 x 16 B in flight per thread (Little's law:
         // 6 TB/s x ~2 us of loaded latency needs ~50 KB in flight per CU).
-        constexpr int LD = ((TR_ROWS + 1) * (TR_MAXW * 4 / 16 + 2) + 255) / 256;  // chunks per thread, upper bound
-        const uint32_t total_chunks = lrows * chunks;
-        const float inv_chunks = 1.0f / (float)chunks;
-        uint4 v[LD];
-        uint32_t dst[LD];
+        // [r4] Which (row, chunk) a load covers is fixed by the thread's index - the workgroup's lower half takes the even staged
+        // rows, the upper half the odd ones, thread t & 127 chunk t & 127 (+ 128 for the widest tiles) - so no load needs a
+        // division: rounds 1-3 cut a flat chunk index into (row, chunk) with a float reciprocal and three 32-bit multiplies (a
+        // quarter of the full vector rate each) per load, a third of the kernel's vector instructions.
+        constexpr int KR = (TR_ROWS + 2) / 2, KC = (TR_MAXW * 4 / 16 + 2 + 127) / 128;  // rows per half, chunk passes
+        static_assert(KC == 2, "chunks of a row fit two passes of 128 threads");
+        const uint32_t half = threadIdx.x >> 7, c0 = threadIdx.x & 127u;
+        uint4 v[KR][KC];
+        bool ok[KR][KC];
+        uint64_t gr = g0 + (uint64_t)half * bpr;  // first byte of this thread's first row segment
 #pragma unroll
-        for (int k = 0; k < LD; k++) {
-            const uint32_t idx = threadIdx.x + 256u * k;
-            dst[k] = ~0u;
-            if (idx < total_chunks) {
-                uint32_t r = (uint32_t)((float)idx * inv_chunks);
-                if (r * chunks > idx) r--;
-                if ((r + 1) * chunks <= idx) r++;
-                const uint32_t ch = idx - r * chunks;
-                const uint64_t gr = g0 + (uint64_t)r * bpr;           // first byte of this row's segment
+        for (int kr = 0; kr < KR; kr++, gr += 2 * bpr) {
+            const uint32_t r = half + 2u * kr;
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+                const uint32_t ch = c0 + 128u * kc;
                 const uint64_t a = (gr & ~15ull) + (uint64_t)ch * 16;  // 16-byte aligned chunk
-                if (a < gr + row_bytes) {
-                    dst[k] = r * TR_PITCH + ch * 16;
-                    if (a + 16 <= raster_bytes) v[k] = *reinterpret_cast<const uint4 *>(raster + a);
+                ok[kr][kc] = r < lrows && ch < chunks && a < gr + row_bytes;
+                if (ok[kr][kc]) {
+                    if (a + 16 <= raster_bytes) v[kr][kc] = *reinterpret_cast<const uint4 *>(raster + a);
                     else {  // last chunk of the raster: stay inside the allocation
                         uint32_t w4[4] = {0, 0, 0, 0};
                         for (uint32_t q = 0; q < 4; q++) if (a + 4 * q + 4 <= raster_bytes) w4[q] = *reinterpret_cast<const uint32_t *>(raster + a + 4 * q);
-                        v[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        v[kr][kc] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < LD; k++) if (dst[k] != ~0u) *reinterpret_cast<uint4 *>(rows + dst[k]) = v[k];
+        for (int kr = 0; kr < KR; kr++)
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+                if (ok[kr][kc]) *reinterpret_cast<uint4 *>(rows + (half + 2u * kr) * TR_PITCH + (c0 + 128u * kc) * 16) = v[kr][kc];
     }
     __syncthreads();
     // ---- phase 2 (dispatch once per workgroup on the tile's predictor flags)
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     }
     const uint64_t lt = lanemask_lt();
     // field of context c in the packed counters: word c / 3, bits [10 * (c % 3), +10)
-    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);
+    const uint32_t myq = __umul24(lane, 11u) >> 5, mysh = __umul24(lane - __umul24(myq, 3u), 10u);
 
     // planes are read one iteration ahead (dwords; the planes carry >= 192 bytes of slack behind a tile)
     uint32_t nx_nl = 0xFFFFFFFFu, nx_r = 0, nx_g = 0, nx_b = 0;
@@ -758,8 +762,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 pl[j] = p;
-                const uint32_t q = (p * 11u) >> 5;
-                sh[j] = 10u * (p - 3u * q);
+                const uint32_t q = __umul24(p, 11u) >> 5;  // (24-bit multiplies: full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it)
+                sh[j] = __umul24(p - __umul24(q, 3u), 10u);
                 const uint32_t one = coded[j] ? 1u << sh[j] : 0u;
                 inc[j][0] = q == 0 ? one : 0u; inc[j][1] = q == 1 ? one : 0u; inc[j][2] = q == 2 ? one : 0u;
                 w0 += inc[j][0]; w1 += inc[j][1]; w2s += inc[j][2];

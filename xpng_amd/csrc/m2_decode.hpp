@@ -336,7 +336,7 @@ __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__res
     if (tid < 9) s_run[tid] = 0;
     if (tid >= 1 && tid < 9) s_off[tid] = (uint32_t)m2_off_stream(t.n, stream_n + (uint64_t)tile * M2_SLOTS, 8 + tid);  // class stream of nl = tid
     __syncthreads();
-    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);  // field of counter `lane` in the packed words
+    const uint32_t myq = __umul24(lane, 11u) >> 5, mysh = __umul24(lane - __umul24(myq, 3u), 10u);  // field of counter `lane` in the packed words
     uint32_t py = (4 * tid) / t.w, px = 4 * tid - py * t.w;   // (x, y) of the lane's first pixel, advanced by PX pixels per iteration
     const uint32_t dy = PX / t.w, dx = PX - dy * t.w;
     for (uint32_t i0 = 0; i0 < t.n; i0 += PX) {
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(THREADS) void k_m2_dec_resid(const M2DecTile *__res
         for (int k = 0; k < 4; k++) {
             coded[k] = i + k < t.n && i + k > 0;
             nl[k] = coded[k] ? min((u >> (8 * k)) & 255u, 8u) : 0u;
-            const uint32_t v = nl[k], q = (v * 11u) >> 5;
-            csh[k] = 10u * (v - 3u * q);
+            const uint32_t v = nl[k], q = __umul24(v, 11u) >> 5;
+            csh[k] = __umul24(v - __umul24(q, 3u), 10u);
             const uint32_t one = v ? 1u << csh[k] : 0u;
             cinc[k][0] = q == 0 ? one : 0u; cinc[k][1] = q == 1 ? one : 0u; cinc[k][2] = q == 2 ? one : 0u;
             c0 += cinc[k][0]; c1 += cinc[k][1]; c2 += cinc[k][2];

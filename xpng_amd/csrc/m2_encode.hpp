@@ -152,7 +152,7 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
     uint32_t run_pl = 0;
     const uint64_t lt = lanemask_lt();
     // field of counter c in the packed words: word c / 3, bits [10 * (c % 3), +10)
-    const uint32_t myq = (lane * 11u) >> 5, mysh = 10u * (lane - 3u * myq);
+    const uint32_t myq = __umul24(lane, 11u) >> 5, mysh = __umul24(lane - __umul24(myq, 3u), 10u);
     uint32_t nx_nl = 0xFFFFFFFFu, nx_r = 0, nx_g = 0, nx_b = 0;
     if (4 * tid < t.n) { nx_nl = pnl[tid]; nx_r = pr_[tid]; nx_g = pg[tid]; nx_b = pb[tid]; }
     for (uint32_t i0 = 0; i0 < t.n; i0 += PX) {
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
             coded[j] = nl[j] != NL_NONE;
             lastnl = coded[j] ? nl[j] : lastnl;
             // class counter of the pixel: field nl (1..8; nl = 0 emits no class symbol)
-            const uint32_t v = coded[j] ? (nl[j] & 15u) : 0u, q = (v * 11u) >> 5;
-            csh[j] = 10u * (v - 3u * q);
+            const uint32_t v = coded[j] ? (nl[j] & 15u) : 0u, q = __umul24(v, 11u) >> 5;
+            csh[j] = __umul24(v - __umul24(q, 3u), 10u);
             const uint32_t one = v ? 1u << csh[j] : 0u;
             cinc[j][0] = q == 0 ? one : 0u; cinc[j][1] = q == 1 ? one : 0u; cinc[j][2] = q == 2 ? one : 0u;
             c0 += cinc[j][0]; c1 += cinc[j][1]; c2 += cinc[j][2];
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(THREADS) void k_m2_streams(const TileDesc *__restri
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 pl[j] = p;
-                const uint32_t q = (p * 11u) >> 5;
-                sh[j] = 10u * (p - 3u * q);
+                const uint32_t q = __umul24(p, 11u) >> 5;  // (24-bit multiplies: full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it)
+                sh[j] = __umul24(p - __umul24(q, 3u), 10u);
                 const uint32_t one = coded[j] ? 1u << sh[j] : 0u;
                 inc[j][0] = q == 0 ? one : 0u; inc[j][1] = q == 1 ? one : 0u; inc[j][2] = q == 2 ? one : 0u;
                 w0 += inc[j][0]; w1 += inc[j][1]; w2s += inc[j][2];
