@@ -170,8 +170,10 @@ __device__ __forceinline__ void rgb_group_interior(const int useGrad, const int 
 // The nine context-stream lengths of a tile are a histogram of its nl plane (k_m1_lens below).  Through round 3 a kernel of its own
 // (k_m1_count) re-read the plane for it: 1 B/px of HBM traffic and a launch on the encode's critical path.  The transform holds every
 // nl it writes, so it counts them itself: a thread keeps packed per-bin counters of its own pixels (NlAcc below), remembers its last
-// group with a coded pixel, and the workgroup adds its nine sums to the tile's
-// counters nlh[tile * NLH_STRIDE + c] and raises nlh[.. + 9] to ((index of its last coded pixel + 1) << 4 | that pixel's nl).
+// group with a coded pixel, and the workgroup leaves its nine sums and ((index of its last coded pixel + 1) << 4 | that pixel's nl) in
+// a record of its own: nlh[(tile * slots + workgroup of the tile) * NLH_STRIDE + 0..9], plain stores.  (A first version added them to
+// per-tile counters with ten atomics per workgroup: 7 M memory-side atomics per 128-raster launch, ~4 % of the transform's time.)
+// k_m1_lens / k_m2_count add a tile's records up (nlh_reduce).
 constexpr uint32_t NLH_STRIDE = 12;  // u32 per tile: nine counts, the last-coded-pixel key, two spare
 #ifndef XPNG_HIST_VARIANT
 #define XPNG_HIST_VARIANT 1
@@ -247,20 +249,43 @@ __device__ __forceinline__ void nlacc_commit(const NlAcc &a, uint32_t (*s_red)[6
             if (tid < 9) v += (tid & 1) ? x >> 16 : x & 0xFFFFu;
             else v = x > v ? x : v;
         }
-        if (v) { if (tid < 9) atomicAdd(nlh_tile + tid, v); else atomicMax(nlh_tile + 9, v); }
+        nlh_tile[tid] = v;  // (this workgroup's own record: every record a launch's reduction reads is written by that launch)
     }
 }
-// counters -> the nine stream lengths (common.hpp: stream-scratch layout): stream c receives the nl of every coded pixel whose
+// records of a tile -> h[0..8] = histogram of its nl plane over coded pixels, h[9] = key of its last coded pixel (0: none), the same in
+// every lane.  One wavefront; nrec = records the transform wrote for this tile (its strips, or its 4096-pixel chunks).
+__device__ __forceinline__ void nlh_reduce(const uint32_t *__restrict__ rec, uint32_t nrec, uint32_t *h) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t r = lane; r < nrec; r += 64) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(rec + (uint64_t)r * NLH_STRIDE);  // (records are 48 bytes: 16-byte aligned)
+        const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+        a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w; a[8] += v2.x;
+        a[9] = v2.y > a[9] ? v2.y : a[9];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) h[c] = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(a[c]), 63);
+    h[9] = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max(a[9]), 63);
+}
+// how many records the transform left for a tile: one per strip of TR_ROWS rows (LDS-staged forms) or per 1024 * TG_REPS pixels
+__host__ __device__ inline uint32_t nlh_records(uint32_t w, uint32_t h, bool generic);
+// records -> the nine stream lengths (common.hpp: stream-scratch layout): stream c receives the nl of every coded pixel whose
 // predecessor (the previous coded pixel; the first one's is 0, libxpng.c:497-508) has nl = c:
 //     len[c] = hist[c] - [c == nl of the last coded pixel] + [c == 0]            (all zero when the tile codes no pixel)
-__global__ __launch_bounds__(256) void k_m1_lens(const uint32_t *__restrict__ nlh, TileSel sel, uint32_t total, uint32_t *__restrict__ ctx_n) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total * 9) return;
-    const uint32_t tile = vtile(sel, j / 9), c = j % 9;
-    const uint32_t l = nlh[(uint64_t)tile * NLH_STRIDE + 9];
-    uint32_t len = nlh[(uint64_t)tile * NLH_STRIDE + c];
-    if (l) len = len - ((l & 15u) == c ? 1u : 0u) + (c == 0 ? 1u : 0u);
-    ctx_n[(uint64_t)tile * 9 + c] = len;
+// grid = tiles, block = 64.
+__global__ __launch_bounds__(64) void k_m1_lens(const uint32_t *__restrict__ nlh, uint32_t slots, uint32_t generic, const TileDesc *__restrict__ tiles,
+                                                TileSel sel, uint32_t *__restrict__ ctx_n) {
+    const uint32_t tile = vtile(sel, blockIdx.x), lane = threadIdx.x & 63;
+    const TileDesc t = tiles[tile];
+    uint32_t h[10];
+    nlh_reduce(nlh + (uint64_t)tile * slots * NLH_STRIDE, nlh_records(t.w, t.h, generic != 0), h);
+    if (lane < 9) {
+        uint32_t len = 0;
+#pragma unroll
+        for (int c = 0; c < 9; c++) len = lane == (uint32_t)c ? h[c] : len;
+        if (h[9]) len = len - ((h[9] & 15u) == lane ? 1u : 0u) + (lane == 0 ? 1u : 0u);
+        ctx_n[(uint64_t)tile * 9 + lane] = len;
+    }
 }
 
 constexpr uint32_t TG_REPS = 4;  // 1024-pixel chunks per workgroup of k_m1_transform_generic
@@ -268,7 +293,7 @@ template <int PXSZ>
 __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                               const TileDesc *__restrict__ tiles, TileSel sel,
                                                               uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
-                                                              uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t *__restrict__ nlh) {
+                                                              uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t *__restrict__ nlh, uint32_t nlh_slots) {
     __shared__ uint32_t s_red[4][6];
     NlAcc hacc = nlacc_zero();
     const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
@@ -322,11 +347,14 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
     if (PXSZ == 4) *reinterpret_cast<uint32_t *>(planes + 4 * plane_stride + o) = oa;
     nlacc_add(hacc, onl, i0);
     }
-    if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE);  // (nlh is a kernel argument: the whole workgroup takes the same side)
+    if (nlh) nlacc_commit<256>(hacc, s_red, nlh + ((uint64_t)tile * nlh_slots + chunk) * NLH_STRIDE);  // (nlh is a kernel argument: the whole workgroup takes the same side)
 }
 
 constexpr uint32_t TR_ROWS = 8, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
 static_assert((TR_ROWS * TR_MAXW / 4 + 255) / 256 <= 7 && TG_REPS <= 7, "NlAcc: a thread's groups per workgroup must fit its 3-bit fields");
+__host__ __device__ inline uint32_t nlh_records(uint32_t w, uint32_t h, bool generic) {
+    return generic ? (w * h + 1024u * TG_REPS - 1) / (1024u * TG_REPS) : (h + TR_ROWS - 1) / TR_ROWS;
+}
 // phase 2 of k_m1_transform_rgba, specialised on the tile's predictor flags so that no per-pixel branch on them remains
 // one group of 4 consecutive pixels of a strip staged in LDS (RGBA): the five packed symbol dwords.  g = group index inside the
 // strip, (yy, x0) = row inside the strip and column of its first pixel.
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
                                                            uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
                                                            uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
                                                            uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks,
-                                                           uint32_t *__restrict__ nlh) {
+                                                           uint32_t *__restrict__ nlh, uint32_t nlh_slots) {
     __shared__ __align__(16) uint8_t rows[(TR_ROWS + 1) * TR_PITCH];
     __shared__ uint32_t s_red[4][6];
     // Consecutive block ids round-robin over the 8 XCDs, each with its own L2; consecutive strips of a tile share a halo row.
@@ -510,7 +538,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
     // ---- phase 2 (dispatch once per workgroup on the tile's predictor flags)
     { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 4, t.w, t.h) & 3) & 3u; NlAcc hacc = nlacc_zero(); transform_phase2((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, y0, first, nrows, planes, plane_stride, hacc);
       XPNG_BURN(g_burn_tr, threadIdx.x + pr_, reinterpret_cast<uint32_t *>(planes));
-      if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE); }
+      if (nlh) nlacc_commit<256>(hacc, s_red, nlh + ((uint64_t)tile * nlh_slots + strip) * NLH_STRIDE); }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -604,7 +632,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
                                                           uint64_t raster_bytes, const TileDesc *__restrict__ tiles, TileSel sel,
                                                           uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
                                                           uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks,
-                                                          uint32_t *__restrict__ nlh) {
+                                                          uint32_t *__restrict__ nlh, uint32_t nlh_slots) {
     __shared__ __align__(16) uint8_t rows[TR3_LDS_PAD + (TR_ROWS + 1) * TR_PITCH + 16];
     __shared__ uint32_t s_red[4][6];
     const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware: consecutive strips of a tile on one XCD
@@ -652,7 +680,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
     }
     __syncthreads();
     { const uint32_t pr_ = (pr_from_sums(sums + (uint64_t)tile * 4, 3, t.w, t.h) & 3) & 3u; NlAcc hacc = nlacc_zero(); transform_phase2_rgb((int)(pr_ >> 1), (int)(pr_ & 1u), rows, t, bpr, g0, y0, first, nrows, planes, plane_stride, hacc);
-      if (nlh) nlacc_commit<256>(hacc, s_red, nlh + (uint64_t)tile * NLH_STRIDE); }
+      if (nlh) nlacc_commit<256>(hacc, s_red, nlh + ((uint64_t)tile * nlh_slots + strip) * NLH_STRIDE); }
 }
 
 // --------------------------------------------------------------------------------------------------

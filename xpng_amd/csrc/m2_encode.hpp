@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_m2_classify(const uint8_t *const *__res
 // candidate streams hold n - 1 symbols each; everything else 0.  The histogram of the nl plane comes from the transform itself
 // (nlh, m1_encode.hpp [r4]: rounds 2-3 re-read the plane here).   grid = tiles, block = 64.
 __global__ __launch_bounds__(64) void k_m2_count(const TileDesc *__restrict__ tiles, TileSel sel, const uint32_t *__restrict__ flags,
-                                                 const uint32_t *__restrict__ nlh, uint32_t *__restrict__ stream_n) {
+                                                 const uint32_t *__restrict__ nlh, uint32_t slots, uint32_t generic, uint32_t *__restrict__ stream_n) {
     const uint32_t tile = vtile(sel, blockIdx.x), tid = threadIdx.x;
     const TileDesc t = tiles[tile];
     const uint32_t f = flags[tile];
@@ -111,13 +111,16 @@ __global__ __launch_bounds__(64) void k_m2_count(const TileDesc *__restrict__ ti
         if (tid < M2_SLOTS) sn[tid] = gray && tid >= 17 ? t.n - 1 : 0u;
         return;
     }
-    const uint32_t *h = nlh + (uint64_t)tile * NLH_STRIDE;
+    uint32_t h[10];
+    nlh_reduce(nlh + (uint64_t)tile * slots * NLH_STRIDE, nlh_records(t.w, t.h, generic != 0), h);
     if (tid < 9) {
-        const uint32_t l = h[9];
-        uint32_t len = h[tid];
-        if (l) len = len - ((l & 15u) == tid ? 1u : 0u) + (tid == 0 ? 1u : 0u);
+        uint32_t hc = 0;
+#pragma unroll
+        for (int c = 0; c < 9; c++) hc = tid == (uint32_t)c ? h[c] : hc;
+        uint32_t len = hc;
+        if (h[9]) len = len - ((h[9] & 15u) == tid ? 1u : 0u) + (tid == 0 ? 1u : 0u);
         sn[tid] = len;
-        if (tid >= 1) sn[8 + tid] = h[tid] * (tid >= 3 ? 3u : 1u);
+        if (tid >= 1) sn[8 + tid] = hc * (tid >= 3 ? 3u : 1u);
     }
     if (tid >= 17 && tid < M2_SLOTS) sn[tid] = 0;
 }

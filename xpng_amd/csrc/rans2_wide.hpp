@@ -31,15 +31,17 @@ __device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 +
 
 // streams [c_first, c_first + c_count) of every tile (the alpha streams, c = 9, are prepared and chained while the stream-
 // formation kernel is still producing the context streams: they only need the transform's alpha plane)
+// (j0: the launch covers work items j0 .. of the enumeration - the alpha streams of the biggest tiles may be coded elsewhere, see
+//  k_rans2_encode_one)
 __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first, uint32_t c_count,
                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                    uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
-                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF) {
+                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF, uint32_t j0) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
-    const uint32_t tile = vtile(sel, blockIdx.x / c_count), c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63;
+    const uint32_t tile = vtile(sel, j0 + blockIdx.x / c_count), c = c_first + blockIdx.x % c_count, lane = threadIdx.x & 63;
     const TileDesc t = tiles[tile];
     uint8_t *sc = scratch + t.sbase;
     const uint8_t *in;
@@ -90,7 +92,7 @@ template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab) {
+                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab, uint32_t j0) {
     constexpr uint32_t TPW = 32;                  // tiles (streams) per wave: every lane carries a state (alpha ran 16 per wave while its tables took 4 KB of LDS each)
     // bytes of one encoder table in LDS: a context stream has the nine symbols nl = 0..8 (the alpha class keeps none there)
     constexpr uint32_t TAB = 144;
@@ -105,11 +107,11 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     XPNG_PROBE_BEGIN()
     const uint32_t lane = threadIdx.x & 63, k = lane >> 1, par = lane & 1;
     const uint32_t c = BIG ? 9 : blockIdx.x % 9, grp = BIG ? blockIdx.x : blockIdx.x / 9;
-    const uint32_t j = grp * TPW + k;
+    const uint32_t j = j0 + grp * TPW + k;
     bool live = k < TPW && j < total;
     if (!BIG) {
         for (uint32_t ts = 0; ts < TPW; ts++) {
-            const uint32_t jj = grp * TPW + ts;
+            const uint32_t jj = j0 + grp * TPW + ts;
             if (jj >= total) break;
             const uint4 *src = reinterpret_cast<const uint4 *>(wtab + (uint64_t)vtile(sel, jj) * WTAB_TILE_BYTES + wtab_off(c));
             uint4 *dst = reinterpret_cast<uint4 *>(ltab + ts * TSTRIDE);

@@ -118,7 +118,7 @@ static void ctx_quiesce(xpnghip_ctx *c) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(c->device) == hipSuccess) {
-        hipStream_t qs[4] = {c->stream, c->enc_side, c->dec.side, c->dec.side2};
+        hipStream_t qs[5] = {c->stream, c->enc_side, c->enc_side2, c->dec.side, c->dec.side2};
         for (hipStream_t q : qs) if (q) (void)hipStreamSynchronize(q);
     }
     if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);

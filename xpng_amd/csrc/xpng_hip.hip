@@ -138,7 +138,10 @@ struct xpnghip_ctx {
     std::vector<void *> h_dec_out_ptrs;
     WPrep *d_wprep = nullptr;   // wide entropy stage: per (tile, stream) record, encoder tables, normalised frequencies
     uint8_t *d_wtab = nullptr;
-    uint32_t n_big = 0;
+    uint32_t nlh_slots = 0, nlh_generic = 0;  // records per tile in d_nlh (m1_encode.hpp); which transform form wrote them last
+    uint32_t n_big = 0, n_top = 0;  // tiles of the biggest size class (>= 3/4 of the largest pixel count); tiles as large as the largest
+    hipStream_t enc_side2 = nullptr;      // the alpha streams of the biggest tiles, a wavefront each, beside the wide chains of the rest
+    hipEvent_t ev_enc_join2 = nullptr;
     uint16_t *d_wF = nullptr;
     // mode 2 (RGB slow level): allocated on first use
     uint8_t *d_scratch2 = nullptr;
@@ -184,6 +187,8 @@ extern "C" void xpnghip_ctx_destroy(xpnghip_ctx *c) {
                     c->d_wprep, c->d_wtab, c->d_wF, c->d_blob_len, c->d_status, c->d_scratch2, c->d_sbase2, c->d_flags2, c->d_stream_n2, c->d_blk2, c->d_mt2, c->d_info2, c->d_tabs2, c->d_w1prep, c->d_w1tab, c->d_w1F};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->enc_side) (void)hipStreamDestroy(c->enc_side);
+    if (c->enc_side2) (void)hipStreamDestroy(c->enc_side2);
+    if (c->ev_enc_join2) (void)hipEventDestroy(c->ev_enc_join2);
     if (c->ev_enc_fork) (void)hipEventDestroy(c->ev_enc_fork);
     if (c->ev_enc_join) (void)hipEventDestroy(c->ev_enc_join);
     decode_ws_free(c->dec);
@@ -232,7 +237,11 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
     // (the stream scratch - 7.5 B/px for a level-1 encode, 8 B/px as the decode's symbol / residual planes: one buffer of the larger
     //  size - and the symbol planes, 4 or 5 B/px, are allocated by the first call that needs them: ensure_scratch, ensure_planes)
     ALLOC(c->d_sums, VN * 16);
-    ALLOC(c->d_nlh, VN * NLH_STRIDE * 4);  // nl histogram + last coded pixel of every tile, filled by the transform (m1_encode.hpp)
+    for (uint64_t i = c->r0; i < c->r1; i++) {
+        const TileDesc &t = c->tiles[i];
+        c->nlh_slots = std::max(c->nlh_slots, std::max(nlh_records(t.w, t.h, false), nlh_records(t.w, t.h, true)));
+    }
+    ALLOC(c->d_nlh, VN * c->nlh_slots * NLH_STRIDE * 4 + 64);  // nl histogram + last coded pixel of every transform workgroup (m1_encode.hpp)
     ALLOC(c->d_ctx_n, VN * 9 * 4);
     ALLOC(c->d_k_n, VN * 4);
     ALLOC(c->d_blk_sz, VN * 10 * 4);
@@ -260,8 +269,8 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
         std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return c->tiles[a].n > c->tiles[b].n; });
         if (hipMemcpy(c->d_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { xpnghip_ctx_destroy(c); return fail("context setup failed"); }
         // size class of the biggest tiles (>= 3/4 of the largest pixel count): the decode walks them beside the rest (m1_decode.hpp)
-        c->n_big = 0;
-        for (uint32_t i : ord) if ((uint64_t)c->tiles[i].n * 4 >= (uint64_t)c->tiles[ord[0]].n * 3) c->n_big++;
+        c->n_big = 0; c->n_top = 0;
+        for (uint32_t i : ord) { if ((uint64_t)c->tiles[i].n * 4 >= (uint64_t)c->tiles[ord[0]].n * 3) c->n_big++; if (c->tiles[i].n == c->tiles[ord[0]].n) c->n_top++; }
     }
     c->stamps = c->d_dbg && probe_env("XPNG_STAMPS") != nullptr;  // (probe builds only)
 #ifdef XPNG_PROBES
@@ -391,21 +400,20 @@ static int launch_transform(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     if (launch_chooser<PXSZ>(c, nimg, t0, t1, s, pad)) return 1;
     XPNG_REQUIRE(c->d_planes, c->d_nlh);
     uint32_t *nlh = hist ? c->d_nlh : nullptr;
-    if (hist) {
-        if (t0 == 0 && t1 == c->tiles.size()) HIPCHK(hipMemsetAsync(c->d_nlh, 0, (uint64_t)nimg * sel.N * NLH_STRIDE * 4, s));
-        else for (uint32_t b = 0; b < nimg; b++) HIPCHK(hipMemsetAsync(c->d_nlh + ((uint64_t)b * sel.N + t0) * NLH_STRIDE, 0, (uint64_t)cnt * NLH_STRIDE * 4, s));
-    }
     uint32_t max_w = 0, max_h = 0;
     for (uint32_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; }
     if (PXSZ == 4 && max_w <= TR_MAXW && !probe_env("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        if (!dbg_skip("transform")) k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_, nlh);
+        if (!dbg_skip("transform")) k_m1_transform_rgba<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 4, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_, nlh, c->nlh_slots);
+        c->nlh_generic = 0;
     } else if (PXSZ == 3 && max_w <= TR_MAXW && !probe_env("XPNG_GENERIC_TRANSFORM")) {
         const uint32_t spt_ = (max_h + TR_ROWS - 1) / TR_ROWS;
-        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_, nlh);
+        k_m1_transform_rgb<<<(total * spt_ + 7) & ~7u, 256, pad, s>>>(c->d_in_ptrs, bpr, c->W * c->H * 3, c->d_tiles, sel, spt_, c->d_sums, c->d_planes, c->plane_stride, total * spt_, nlh, c->nlh_slots);
+        c->nlh_generic = 0;
     } else {
         const uint32_t bpt = (max_n + 1024 * TG_REPS - 1) / (1024 * TG_REPS);
-        k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride, nlh);
+        k_m1_transform_generic<PXSZ><<<total * bpt, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, bpt, c->d_sums, c->d_planes, c->plane_stride, nlh, c->nlh_slots);
+        c->nlh_generic = 1;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -456,25 +464,46 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr, true)) return 1;
     // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
     // preparation and the chains themselves run on their own stream behind the transform
+    // Size classes of the alpha chains [r4].  The wide chain kernel lasts as long as its longest chain (the biggest tile: 148 k
+    // steps of ~400 cycles at 4096^2); the wave-per-stream form steps in ~176.  So the alpha streams of the biggest size class
+    // (the first n_big tiles of the sorted enumeration x every image) get a wavefront each on a third stream - histogram, tables,
+    // chain and block in one kernel - and the wide launch is left with tiles whose chains are two thirds as long.  Each such
+    // wavefront holds 26.8 KB of LDS (five to a compute unit), so the class is taken whole only while it fits the chip at once
+    // (<= 1152 wavefronts); otherwise only the tiles as large as the largest are.
+    uint32_t jb = 0;
+    if (alpha_side && sel.order && !getenv("XPNG_NO_SPLIT") && !probe_env("XPNG_NO_ENC_SPLIT")) {
+        const uint32_t nb = (uint64_t)c->n_big * nimg <= 1152 ? c->n_big : ((uint64_t)c->n_top * nimg <= 1152 ? c->n_top : 0u);
+        if (nb > 0 && nb < cnt) jb = nb * nimg;
+    }
+    if (jb && !c->enc_side2) {
+        HIPCHK(chain_stream_create(&c->enc_side2));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join2, hipEventDisableTiming));
+    }
     if (alpha_side) {
         HIPCHK(hipEventRecord(c->ev_enc_fork, s));
         HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
         hipStream_t as = c->enc_side;
-        if (!dbg_skip("prep_a")) k_rans2_prep<<<total, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        if (jb) {
+            HIPCHK(hipStreamWaitEvent(c->enc_side2, c->ev_enc_fork, 0));
+            if (!dbg_skip("chain_a")) k_rans2_encode_one<<<jb, 64, 0, c->enc_side2>>>(c->d_tiles, sel, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep);
+            HIPCHK(hipEventRecord(c->ev_enc_join2, c->enc_side2));
+        }
+        if (!dbg_skip("prep_a")) k_rans2_prep<<<total - jb, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, jb);
+        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total - jb + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, jb);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
     }
     // stream lengths (from the histogram of the nl plane the transform took as it wrote it) -> places of the nine context streams -> routing
-    k_m1_lens<<<(total * 9 + 255) / 256, 256, 0, s>>>(c->d_nlh, sel, total, c->d_ctx_n);
+    k_m1_lens<<<total, 64, 0, s>>>(c->d_nlh, c->nlh_slots, c->nlh_generic, c->d_tiles, sel, c->d_ctx_n);
     if (dbg_skip("streams")) {} else if (small_wg) k_m1_streams<PXSZ, 256><<<total, 256, pad_st, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     if (narrow) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF);
-        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab);
+        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, 0);
+        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, 0);
         if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
+        if (jb) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join2, 0));
         if (!dbg_skip("finish")) k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
     }
     k_tile_sizes<<<(total + 255) / 256, 256, 0, s>>>(c->d_tiles, sel, total, PXSZ, c->spt, c->d_sums, c->d_k_n, c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr);
@@ -517,7 +546,7 @@ static int launch_encode_m2(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     k_m2_classify<<<total * 16, 256, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, 16, c->d_flags2);
     if (launch_transform<3>(c, nimg, t0, t1, s, 0, true)) return 1;  // chooser (PXSZ = 3, libxpng.c:663) + residual planes (allocates them on first use) + nl histogram
     XPNG_REQUIRE(c->d_planes);
-    k_m2_count<<<total, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_nlh, c->d_stream_n2);  // stream lengths -> where every stream goes
+    k_m2_count<<<total, 64, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_nlh, c->nlh_slots, c->nlh_generic, c->d_stream_n2);  // stream lengths -> where every stream goes
     if ((uint64_t)total * M2_STREAMS > 2048 && !probe_env("XPNG_BIG_BLOCKS")) k_m2_streams<256><<<total, 256, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     else k_m2_streams<1024><<<total, 1024, 0, s>>>(c->d_tiles, sel, c->d_flags2, c->d_planes, c->plane_stride, c->d_scratch2, c->d_sbase2, c->d_stream_n2);
     const uint32_t gbpt = (max_n + 256 * M2_GRAY_REPS - 1) / (256 * M2_GRAY_REPS);
