@@ -850,7 +850,8 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 constexpr size_t WALK_WIDE_LDS_BYTES = 10 * 64 * 16 + 10 * 16 * 64 * 4;  // heads + windows (k_dec_walk_wide)
 __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
-                                                      uint8_t *__restrict__ nlseq, uint32_t j0) {
+                                                      uint8_t *__restrict__ nlseq, uint32_t j0, uint32_t lpw) {
+    // (lpw: lanes of a wavefront that carry a tile - 64; fewer only in timing studies: fewer scattered lines per service)
     // window: WCH chunks of 16 B per queue; a queue is serviced every SVC-th block.  (8 chunks / every 4th block is ~8 % faster
     // alone, but 90 KB of LDS per wave instead of 50 costs the kernels beside it more than that.)
     constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;
@@ -860,8 +861,8 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
     uint32_t *const ringw = reinterpret_cast<uint32_t *>(walk_wide_lds + 10 * 64 * 16);     // [10 * WDW * 64]
     __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     XPNG_PROBE_BEGIN()
-    const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * 64 + lane;  // work items [j0, total_tiles)
-    bool live = j < total_tiles;
+    const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * lpw + lane;  // work items [j0, total_tiles)
+    bool live = lane < lpw && j < total_tiles;
     const DecTile *d = info + (live ? j : 0);
     live = live && d->type != 0 && d->type != TILE_BAD;
     const TileDesc *t = tiles + vtile(sel, live ? j : 0);
@@ -1753,6 +1754,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // 43 -> 51 Gpx/s, combined bench +4 % (XPNG_RECON_LDS_PAD=0 turns it off)
     const size_t dbg_pad = probe_pad("XPNG_RECON_LDS_PAD");
     const size_t pad_rs = probe_pad("XPNG_PAD_RS");
+    const uint32_t lpw = probe_pad("XPNG_WALK_LPW") >= 8 && probe_pad("XPNG_WALK_LPW") <= 64 ? (uint32_t)probe_pad("XPNG_WALK_LPW") : 64u;
     if (split) {
         if (!ws.side2) {
             if (chain_stream_create(&ws.side2) != hipSuccess ||
@@ -1761,11 +1763,11 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                 return bad("stream/event creation failed");
         }
         if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
-        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + lpw - 1) / lpw, 64, WALK_WIDE_LDS_BYTES + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb, lpw);
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
-        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0, 64u);
         else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
@@ -1777,7 +1779,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
             k_dec_recon_band<3><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb, total);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
-    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
+    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0, 64u);
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4 && hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");

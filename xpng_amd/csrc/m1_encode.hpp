@@ -714,7 +714,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     uint32_t *kw = reinterpret_cast<uint32_t *>(sc + off_kw(t.n));
 
     constexpr int ST_WAVES = ST_THREADS / 64, ST_PX = ST_THREADS * 4, ST_WORDS = ST_PX * 24 / 32 + 4, ST_ROUNDS = (ST_WORDS + ST_THREADS - 1) / ST_THREADS;
-    __shared__ uint32_t s_bits[ST_WORDS];
+    __shared__ uint32_t s_bits[2][ST_WORDS];  // two bit windows, used alternately: an iteration's window is cleared by the threads that flush it, its partial last word opens the other one [r4: no barrier between the flush and the next iteration]
     __shared__ uint32_t s_run_cnt[9];  // next free byte of every context stream, relative to the tile's scratch (starts at the stream's place)
     __shared__ uint32_t s_wave_cnt[ST_WAVES][9];
     __shared__ volatile uint32_t s_base[ST_WAVES][16];
@@ -724,14 +724,14 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     // first pixel: 8*PXSZ raw bits at the head of k (libxpng.c:547)
     const uint8_t *p0 = raster + (uint64_t)t.y * bpr + (uint64_t)t.x * PXSZ;
     uint32_t run_bits, wbase, run_pl = 0;  // uniform across the workgroup
-    for (int j = tid; j < ST_WORDS; j += ST_THREADS) s_bits[j] = 0;
+    for (int j = tid; j < 2 * ST_WORDS; j += ST_THREADS) (&s_bits[0][0])[j] = 0;
     if (tid < 9) s_run_cnt[tid] = (uint32_t)off_ctx(t.n, ctx_n + (uint64_t)tile * 9, (int)tid);
     __syncthreads();
     if (PXSZ == 4) {
         if (tid == 0) kw[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8) | p0[3];
         run_bits = 32; wbase = 1;
     } else {
-        if (tid == 0) s_bits[0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8);
+        if (tid == 0) s_bits[0][0] = ((uint32_t)p0[0] << 24) | ((uint32_t)p0[1] << 16) | ((uint32_t)p0[2] << 8);
         run_bits = 24; wbase = 0;
     }
     const uint64_t lt = lanemask_lt();
@@ -742,7 +742,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
     uint32_t nx_nl = 0xFFFFFFFFu, nx_r = 0, nx_g = 0, nx_b = 0;
     if (4 * tid < t.n) { nx_nl = pnl[tid]; nx_r = pr_[tid]; nx_g = pg[tid]; nx_b = pb[tid]; }
 
-    for (uint32_t i0 = 0; i0 < t.n; i0 += ST_PX) {
+    uint32_t wpar = 0;  // which bit window this iteration fills
+    for (uint32_t i0 = 0; i0 < t.n; i0 += ST_PX, wpar ^= 1) {
         const uint32_t i = i0 + 4 * tid;
         uint32_t nl4 = nx_nl;
         const uint32_t r4 = nx_r, g4 = nx_g, b4 = nx_b;
@@ -813,10 +814,10 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t e0 = x0 - w0, e1 = x1 - w1, e2 = x2 - w2s;  // exclusive lane prefixes, advanced pixel by pixel below
-        unsigned __int128 frame = 0;
         uint32_t pos = (run_bits & 31) + bit_base + (incl - lane_len);
         const uint32_t wi = pos >> 5;
         pos &= 31;
+        uint32_t fv[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (coded[j]) {
@@ -826,41 +827,60 @@ __global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const 
             }
             e0 += inc[j][0]; e1 += inc[j][1]; e2 += inc[j][2];
             const uint32_t n1 = nl[j] & 15u;  // (NL_NONE has len 0: v is masked out below)
-            const uint32_t v = len[j] ? ((((r4 >> (8 * j)) & 255u) << (2 * n1)) | (((g4 >> (8 * j)) & 255u) << n1) | ((b4 >> (8 * j)) & 255u)) : 0u;
-            frame |= (unsigned __int128)v << ((128u - pos - len[j]) & 127u);
-            pos += len[j];
+            fv[j] = len[j] ? ((((r4 >> (8 * j)) & 255u) << (2 * n1)) | (((g4 >> (8 * j)) & 255u) << n1) | ((b4 >> (8 * j)) & 255u)) : 0u;
         }
         {
-            const uint32_t f0 = (uint32_t)(frame >> 96), f1 = (uint32_t)(frame >> 64), f2 = (uint32_t)(frame >> 32), f3 = (uint32_t)frame;
-            if (f0) atomicOr(&s_bits[wi], f0);
-            if (f1) atomicOr(&s_bits[wi + 1], f1);
-            if (f2) atomicOr(&s_bits[wi + 2], f2);
-            if (f3) atomicOr(&s_bits[wi + 3], f3);
+            // The lane's bit string (its four fields, first pixel first, <= 96 bits) left-aligned in m0:m1:m2, built from the LAST field
+            // backwards: every field is prepended by one funnel shift to the right per word (rounds 1-3 placed each field with a
+            // 128-bit shift of its own: ~60 vector instructions per lane and iteration, a quarter of them at half rate), then the
+            // string moves `pos` bits to the right into the four words it is OR-ed into.  (A field of length 0 is 0: the shift by
+            // (32 - 0) & 31 = 0 of nothing is nothing.)
+            uint32_t m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+                const uint32_t l = len[j];
+                m2 = __builtin_amdgcn_alignbit(m1, m2, l);
+                m1 = __builtin_amdgcn_alignbit(m0, m1, l);
+                m0 = (m0 >> l) | (fv[j] << ((32u - l) & 31u));
+            }
+            const uint32_t f0 = m0 >> pos, f1 = __builtin_amdgcn_alignbit(m0, m1, pos), f2 = __builtin_amdgcn_alignbit(m1, m2, pos), f3 = __builtin_amdgcn_alignbit(m2, 0u, pos);
+            uint32_t *win = s_bits[wpar];
+            if (f0) atomicOr(&win[wi], f0);
+            if (f1) atomicOr(&win[wi + 1], f1);
+            if (f2) atomicOr(&win[wi + 2], f2);
+            if (f3) atomicOr(&win[wi + 3], f3);
         }
         __syncthreads();  // (C) bit window complete
 
         const uint32_t nfull = ((run_bits & 31) + bits_total) >> 5;
-        uint32_t keep[ST_ROUNDS], carry_word = 0;
+        {
+            // whole words leave for k; the thread that reads a word clears it; the one that holds the partial last word (index nfull)
+            // moves it to word 0 of the OTHER window, which the flush of the iteration before this one left all zero
+            uint32_t *win = s_bits[wpar], *nwin = s_bits[wpar ^ 1];
 #pragma unroll
-        for (int k = 0; k < ST_ROUNDS; k++) { const uint32_t j = tid + k * ST_THREADS; keep[k] = j < (uint32_t)ST_WORDS ? s_bits[j] : 0u; }
-        if (tid == 0) carry_word = s_bits[nfull];
-        uint32_t tot_c = 0;
-        if (tid < 9) { for (int w = 0; w < ST_WAVES; w++) tot_c += s_wave_cnt[w][tid]; }
-        __syncthreads();  // (D) everyone has read the window / counts
-#pragma unroll
-        for (int k = 0; k < ST_ROUNDS; k++) {
-            const uint32_t j = tid + k * ST_THREADS;
-            if (j < nfull) kw[wbase + j] = keep[k];
-            if (j < (uint32_t)ST_WORDS) s_bits[j] = j == 0 ? carry_word : 0u;
+            for (int k = 0; k < ST_ROUNDS; k++) {
+                const uint32_t j = tid + k * ST_THREADS;
+                if (j < (uint32_t)ST_WORDS) {
+                    const uint32_t v = win[j];
+                    win[j] = 0u;
+                    if (j < nfull) kw[wbase + j] = v;
+                    else if (j == nfull) nwin[0] = v;
+                }
+            }
         }
-        if (tid < 9) s_run_cnt[tid] += tot_c;
+        if (tid < 9) {
+            uint32_t tot_c = 0;
+            for (int w = 0; w < ST_WAVES; w++) tot_c += s_wave_cnt[w][tid];
+            s_run_cnt[tid] += tot_c;
+        }
         run_bits += bits_total; wbase += nfull; run_pl = new_run_pl;
-        // the next iteration's barrier (A) orders these LDS writes before their next use
+        // (no barrier here: the next iteration ORs into the other window only behind its barriers (A) and (B), and the LDS words this
+        //  iteration's tail reads - the per-wave counts, the window - are rewritten only behind barrier (A) of the next)
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t words = wbase;
-        if (run_bits & 31) { kw[wbase] = s_bits[0]; words++; }  // BITSTREAM_END: tail is already left-aligned
+        if (run_bits & 31) { kw[wbase] = s_bits[wpar][0]; words++; }  // BITSTREAM_END: tail is already left-aligned (it opened the window the next iteration would have filled)
         k_n[tile] = words;
     }
 }

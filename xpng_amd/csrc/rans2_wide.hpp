@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 +
 // streams [c_first, c_first + c_count) of every tile (the alpha streams, c = 9, are prepared and chained while the stream-
 // formation kernel is still producing the context streams: they only need the transform's alpha plane)
 // (j0: the launch covers work items j0 .. of the enumeration - the alpha streams of the biggest tiles may be coded elsewhere, see
-//  k_rans2_encode_one)
+//  k_rans2_encode, tile_container.hpp)
 __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first, uint32_t c_count,
                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,

@@ -12,15 +12,24 @@ namespace xpng {
 
 // K4  one wavefront per (tile, stream): the entropy stage of enc_1_th (libxpng.c:558-559).
 // Stream c < 9: context stream c, alphabet 9, PROB_BITS 12.  Stream 9 (RGBA): alpha symbols = plane `a`
-// from index 1, alphabet 256, PROB_BITS 15.      grid = tiles * spt, block = 64.
-__global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t spt,
+// from index 1, alphabet 256, PROB_BITS 15.      grid = work items * c_count, block = 64: streams [c_first, c_first + c_count)
+// of the first grid / c_count work items of the enumeration.
+// Two uses.  (1) A few tiles (one image): every stream of every tile, the whole entropy stage of the encode.  (2) Beside the wide
+// form of a batch [r4]: ONE stream class - alpha, c_first = 9 - of the first work items of the size-sorted enumeration, i.e. of the
+// biggest tiles.  A wide chain kernel lasts as long as its longest chain and a lane-per-state step takes ~400 cycles against ~176
+// here: with the alpha streams of the biggest size class (>= 3/4 of the largest tile: 17 of a 4096^2 image's 81) a wavefront each,
+// the wide launch of the rest ends with the 444 x 444 tiles' chains - two thirds of the longest.  The block is final when this
+// kernel is done (header, states, table, raw fallback): prep[] (when given) says so and k_rans2_finish leaves it alone.
+// (ONE kernel for both uses: with two callers the compiler stops inlining rans2_encode_block and its hand-scheduled loop becomes a
+//  function call - the single-image encode went from 11.5 to 14.7 ms when a second kernel called it.)
+__global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c_first, uint32_t c_count,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                     uint32_t *__restrict__ blk_sz, uint64_t *__restrict__ dbg) {
+                                                     uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep, uint64_t *__restrict__ dbg) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
-    const uint32_t tile = vtile(sel, blockIdx.x / spt), c = blockIdx.x % spt;
+    const uint32_t tile = vtile(sel, blockIdx.x / c_count), c = c_first + blockIdx.x % c_count;
     const TileDesc t = tiles[tile];
     uint8_t *sc = scratch + t.sbase;
     const uint8_t *in;
@@ -30,31 +39,7 @@ __global__ __launch_bounds__(64) void k_rans2_encode(const TileDesc *__restrict_
     else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
     const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c), hist, cum, tab,
                                            dbg ? dbg + ((uint64_t)tile * 10 + c) * 8 : nullptr);
-    if ((threadIdx.x & 63) == 0) blk_sz[(uint64_t)tile * 10 + c] = sz;
-}
-
-// The same for ONE stream class of the first `cnt` work items of the enumeration (sorted by size: the biggest tiles), beside the
-// wide form of everything else [r4].  A wide chain kernel lasts as long as its longest chain and a lane-per-state step takes ~400
-// cycles against ~176 here: the alpha streams of the biggest size class (>= 3/4 of the largest tile: 17 of a 4096^2 image's 81)
-// get a wavefront each and the launch of the rest ends with the 444 x 444 tiles' chains - two thirds of the longest.  The block is
-// final when this kernel is done (header, states, table, raw fallback): prep[] says so and k_rans2_finish leaves it alone.
-__global__ __launch_bounds__(64) void k_rans2_encode_one(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t c,
-                                                         const uint8_t *__restrict__ planes, uint64_t plane_stride,
-                                                         uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                         uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t cum[260];
-    __shared__ EncSym tab[256];
-    const uint32_t tile = vtile(sel, blockIdx.x);
-    const TileDesc t = tiles[tile];
-    uint8_t *sc = scratch + t.sbase;
-    const uint8_t *in;
-    uint32_t n, nominalN;
-    int pb;
-    if (c < 9) { in = sc + off_ctx(t.n, ctx_n + (uint64_t)tile * 9, (int)c); n = ctx_n[(uint64_t)tile * 9 + c]; nominalN = 9; pb = 12; }
-    else { in = planes + 4 * plane_stride + t.pbase + 1; n = t.n - 1; nominalN = 256; pb = 15; }
-    const uint32_t sz = rans2_encode_block(in, n, nominalN, pb, sc + off_blk(t.n, ctx_n + (uint64_t)tile * 9, (int)c), hist, cum, tab, nullptr);
-    if ((threadIdx.x & 63) == 0) { blk_sz[(uint64_t)tile * 10 + c] = sz; prep[(uint64_t)tile * 10 + c].kind = 0; }
+    if ((threadIdx.x & 63) == 0) { blk_sz[(uint64_t)tile * 10 + c] = sz; if (prep) prep[(uint64_t)tile * 10 + c].kind = 0; }
 }
 
 // K5a  per-tile size + header word.  One thread per tile.

@@ -485,7 +485,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         hipStream_t as = c->enc_side;
         if (jb) {
             HIPCHK(hipStreamWaitEvent(c->enc_side2, c->ev_enc_fork, 0));
-            if (!dbg_skip("chain_a")) k_rans2_encode_one<<<jb, 64, 0, c->enc_side2>>>(c->d_tiles, sel, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep);
+            if (!dbg_skip("chain_a")) k_rans2_encode<<<jb, 64, 0, c->enc_side2>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, nullptr);
             HIPCHK(hipEventRecord(c->ev_enc_join2, c->enc_side2));
         }
         if (!dbg_skip("prep_a")) k_rans2_prep<<<total - jb, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, jb);
@@ -498,7 +498,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     else k_m1_streams<PXSZ, 1024><<<total, 1024, 0, s>>>(c->d_in_ptrs, bpr, c->d_tiles, sel, c->d_planes, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_k_n);
     if (narrow) {
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
-        k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->stamps ? c->d_dbg : nullptr);
+        k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, 0, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, nullptr, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
         if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, 0);
         if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, 0);
