@@ -847,22 +847,30 @@ __global__ __launch_bounds__(64) void k_dec_walk(const DecTile *__restrict__ inf
 // the previous step are forwarded instead.  Queue 9 is a parking queue that returns 9 forever: a lane whose tile is
 // finished walks it.  Global memory is touched only at 16-step block boundaries: aligned 16-byte chunks are requested for a
 // queue at one service and land in its window at the next (the chunk starts are 16-byte aligned, k_dec_parse).
-constexpr size_t WALK_WIDE_LDS_BYTES = 10 * 64 * 16 + 10 * 16 * 64 * 4;  // heads + windows (k_dec_walk_wide)
+// LPW = tiles per wavefront (lanes 0 .. LPW - 1 carry one each, the others idle through the loop): the LDS of a wavefront is 800 LPW
+// bytes - 51 KB at 64.  [r4] A workgroup that asks for 51 KB is placed only when a compute unit has that much free at once, and the
+// chip-filling kernels of the other pipeline slots re-occupy every smaller hole at once: profiles/r03_wave_probe_p4.txt has the
+// wide walk's wavefronts starting up to 6 (p90) / 10 ms (max) after the first one - on the decode's critical path, a kernel of ~20 ms
+// of work spans ~30.  With 32 tiles per wavefront a workgroup asks for 25.6 KB (and waits for 288 scattered lines per service
+// instead of 576); the price is twice the wavefronts, i.e. twice the walk's vector instructions.
+constexpr uint32_t WALK_WIDE_COLS(uint32_t lpw) { return lpw + (lpw < 64 ? 1u : 0u); }  // LDS columns: one per tile + one that the idle lanes share
+constexpr size_t WALK_WIDE_LDS_BYTES(uint32_t lpw) { return 10 * (size_t)WALK_WIDE_COLS(lpw) * 16 + 10 * 16 * (size_t)WALK_WIDE_COLS(lpw) * 4; }  // heads + windows (k_dec_walk_wide)
+template <uint32_t LPW>
 __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                       TileSel sel, uint32_t total_tiles, const uint8_t *__restrict__ ctxsym,
-                                                      uint8_t *__restrict__ nlseq, uint32_t j0, uint32_t lpw) {
-    // (lpw: lanes of a wavefront that carry a tile - 64; fewer only in timing studies: fewer scattered lines per service)
+                                                      uint8_t *__restrict__ nlseq, uint32_t j0) {
     // window: WCH chunks of 16 B per queue; a queue is serviced every SVC-th block.  (8 chunks / every 4th block is ~8 % faster
     // alone, but 90 KB of LDS per wave instead of 50 costs the kernels beside it more than that.)
-    constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4;
-    static_assert(WALK_WIDE_LDS_BYTES == 10 * 64 * 16 + 10 * WDW * 64 * 4, "LDS layout");
+    constexpr uint32_t WCH = 4, SVC = 2, WDW = WCH * 4, lpw = LPW, COLS = WALK_WIDE_COLS(LPW);
+    static_assert(WALK_WIDE_LDS_BYTES(LPW) == 10 * COLS * 16 + 10 * WDW * COLS * 4 && LPW >= 8 && LPW <= 64, "LDS layout");
     extern __shared__ __align__(16) uint8_t walk_wide_lds[];  // dynamic (common.hpp: why)
-    u32x4_t *const head = reinterpret_cast<u32x4_t *>(walk_wide_lds);                        // [10 * 64]
-    uint32_t *const ringw = reinterpret_cast<uint32_t *>(walk_wide_lds + 10 * 64 * 16);     // [10 * WDW * 64]
+    u32x4_t *const head = reinterpret_cast<u32x4_t *>(walk_wide_lds);                         // [10 * COLS]
+    uint32_t *const ringw = reinterpret_cast<uint32_t *>(walk_wide_lds + 10 * COLS * 16);    // [10 * WDW * COLS]
     __builtin_amdgcn_s_setprio(XPNG_CHAIN_PRIO);  // a serial chain: its latency is the critical path, the throughput kernels beside it are not
     XPNG_PROBE_BEGIN()
-    const uint32_t lane = threadIdx.x & 63, j = j0 + blockIdx.x * lpw + lane;  // work items [j0, total_tiles)
-    bool live = lane < lpw && j < total_tiles;
+    const uint32_t lane_ = threadIdx.x & 63, j = j0 + blockIdx.x * lpw + lane_;  // work items [j0, total_tiles)
+    bool live = lane_ < lpw && j < total_tiles;
+    const uint32_t lane = lane_ < lpw ? lane_ : lpw;  // LDS column of this lane (the idle lanes of a narrower form share the last one: they only ever walk the parking queue, whose heads are self-consistent whoever wrote them)
     const DecTile *d = info + (live ? j : 0);
     live = live && d->type != 0 && d->type != TILE_BAD;
     const TileDesc *t = tiles + vtile(sel, live ? j : 0);
@@ -886,17 +894,17 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
         for (int q = 0; q < (int)SVC; q++) {
             u32x4_t v = zero4;
             if (live) v = src[q];
-            ringw[(c * WDW + q * 4 + 0) * 64 + lane] = v.x; ringw[(c * WDW + q * 4 + 1) * 64 + lane] = v.y;
-            ringw[(c * WDW + q * 4 + 2) * 64 + lane] = v.z; ringw[(c * WDW + q * 4 + 3) * 64 + lane] = v.w;
-            if (q == 0) { const u32x4_t h = {v.x, 0u, v.y, 0u}; head[c * 64 + lane] = h; }
+            ringw[(c * WDW + q * 4 + 0) * COLS + lane] = v.x; ringw[(c * WDW + q * 4 + 1) * COLS + lane] = v.y;
+            ringw[(c * WDW + q * 4 + 2) * COLS + lane] = v.z; ringw[(c * WDW + q * 4 + 3) * COLS + lane] = v.w;
+            if (q == 0) { const u32x4_t h = {v.x, 0u, v.y, 0u}; head[c * COLS + lane] = h; }
         }
         have[c] = SVC;
 #pragma unroll
         for (int q = 0; q < (int)SVC; q++) { fl[c][q] = zero4; if (live) fl[c][q] = src[SVC + q]; }
     }
 #pragma unroll
-    for (int w = 0; w < (int)WDW; w++) ringw[(9 * WDW + w) * 64 + lane] = 0x09090909u;
-    { const u32x4_t h = {0x09090909u, 0u, 0x09090909u, 0u}; head[9 * 64 + lane] = h; }
+    for (int w = 0; w < (int)WDW; w++) ringw[(9 * WDW + w) * COLS + lane] = 0x09090909u;
+    { const u32x4_t h = {0x09090909u, 0u, 0x09090909u, 0u}; head[9 * COLS + lane] = h; }
     uint32_t T = total;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(T, o); T = v > T ? v : T; }
@@ -912,10 +920,10 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
             // flight together
             const uint32_t npos = ppos + 1;
             const bool cross = (npos & 3u) == 0;
-            const uint32_t rr = ringw[(pcur * WDW + (((npos >> 2) + 1) & (WDW - 1))) * 64 + lane];
-            const u32x4_t r = head[cur * 64 + lane];               // (stale if cur == pcur: forwarded below)
+            const uint32_t rr = ringw[(pcur * WDW + (((npos >> 2) + 1) & (WDW - 1))) * COLS + lane];
+            const u32x4_t r = head[cur * COLS + lane];               // (stale if cur == pcur: forwarded below)
             const uint32_t nlo = cross ? pnxt : plo >> 8, nnxt = cross ? rr : pnxt;
-            { const u32x4_t h = {nlo, npos, nnxt, 0u}; head[pcur * 64 + lane] = h; }
+            { const u32x4_t h = {nlo, npos, nnxt, 0u}; head[pcur * COLS + lane] = h; }
             const bool same = cur == pcur;
             plo = same ? nlo : r.x; ppos = same ? npos : r.y; pnxt = same ? nnxt : (r.z | r.w);  // (r.w == 0; keeps the 4th register of the read alive so nothing else is loaded into it early)
             pcur = cur;
@@ -937,12 +945,12 @@ __global__ __launch_bounds__(64) void k_dec_walk_wide(const DecTile *__restrict_
 #pragma unroll
         for (int c = 0; c < 9; c++) {
             if ((c & (int)(SVC - 1)) != phase) continue;
-            const uint32_t cq = head[c * 64 + lane].y >> 4;  // chunk the queue is reading from
+            const uint32_t cq = head[c * COLS + lane].y >> 4;  // chunk the queue is reading from
 #pragma unroll
             for (int q = 0; q < (int)SVC; q++) {
                 if (have[c] - cq < WCH) {  // (once one chunk does not fit, neither do the later ones: have stops growing)
-                    const uint32_t w0 = (c * WDW + (have[c] & (WCH - 1)) * 4) * 64 + lane;
-                    ringw[w0] = fl[c][q].x; ringw[w0 + 64] = fl[c][q].y; ringw[w0 + 128] = fl[c][q].z; ringw[w0 + 192] = fl[c][q].w;
+                    const uint32_t w0 = (c * WDW + (have[c] & (WCH - 1)) * 4) * COLS + lane;
+                    ringw[w0] = fl[c][q].x; ringw[w0 + COLS] = fl[c][q].y; ringw[w0 + 2 * COLS] = fl[c][q].z; ringw[w0 + 3 * COLS] = fl[c][q].w;
                     have[c]++;
                 }
             }
@@ -1754,7 +1762,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     // 43 -> 51 Gpx/s, combined bench +4 % (XPNG_RECON_LDS_PAD=0 turns it off)
     const size_t dbg_pad = probe_pad("XPNG_RECON_LDS_PAD");
     const size_t pad_rs = probe_pad("XPNG_PAD_RS");
-    const uint32_t lpw = probe_pad("XPNG_WALK_LPW") >= 8 && probe_pad("XPNG_WALK_LPW") <= 64 ? (uint32_t)probe_pad("XPNG_WALK_LPW") : 64u;
+    const uint32_t lpw = probe_env("XPNG_WALK_LPW") ? (uint32_t)atoi(probe_env("XPNG_WALK_LPW")) : 64u;  // tiles per wavefront of the small-tile walk: 64, or (probe builds) 32 / 16 - the same bytes
     if (split) {
         if (!ws.side2) {
             if (chain_stream_create(&ws.side2) != hipSuccess ||
@@ -1763,11 +1771,15 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
                 return bad("stream/event creation failed");
         }
         if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
-        if (!dbg_skip("walk_small")) k_dec_walk_wide<<<(total - jb + lpw - 1) / lpw, 64, WALK_WIDE_LDS_BYTES + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb, lpw);
+        if (!dbg_skip("walk_small")) {
+            if (lpw == 32) k_dec_walk_wide<32><<<(total - jb + 31) / 32, 64, WALK_WIDE_LDS_BYTES(32) + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+            else if (lpw == 16) k_dec_walk_wide<16><<<(total - jb + 15) / 16, 64, WALK_WIDE_LDS_BYTES(16) + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+            else k_dec_walk_wide<64><<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64) + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+        }
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
-        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0, 64u);
+        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<64><<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64), s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
         else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
         if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
@@ -1779,7 +1791,7 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
             k_dec_recon_band<3><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb, total);
         }
         if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
-    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES, s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0, 64u);
+    } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<64><<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64), s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
     const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
     if (pxsz == 4 && hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");

@@ -464,14 +464,15 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     if (launch_transform<PXSZ>(c, nimg, t0, t1, s, pad_tr, true)) return 1;
     // Wide form, RGBA: the alpha chains are the longest serial stage of the encode and need only the alpha plane, so their
     // preparation and the chains themselves run on their own stream behind the transform
-    // Size classes of the alpha chains [r4].  The wide chain kernel lasts as long as its longest chain (the biggest tile: 148 k
-    // steps of ~400 cycles at 4096^2); the wave-per-stream form steps in ~176.  So the alpha streams of the biggest size class
-    // (the first n_big tiles of the sorted enumeration x every image) get a wavefront each on a third stream - histogram, tables,
-    // chain and block in one kernel - and the wide launch is left with tiles whose chains are two thirds as long.  Each such
-    // wavefront holds 26.8 KB of LDS (five to a compute unit), so the class is taken whole only while it fits the chip at once
-    // (<= 1152 wavefronts); otherwise only the tiles as large as the largest are.
+    // Size classes of the alpha chains: an experiment of round 4 that LOST (probe builds: XPNG_ENC_SPLIT=1).  The wide chain kernel lasts
+    // as long as its longest chain (the biggest tile: 148 k steps of ~400 cycles at 4096^2; the median wavefront of a launch ends after two
+    // thirds of that) and the wave-per-stream form steps in ~176 cycles, so the alpha streams of the biggest size class (the first n_big
+    // tiles of the sorted enumeration x every image) were given a wavefront each on a third stream, k_rans2_encode with c_first = 9.
+    // Bit-exact, 67 GPU tests green - and 33.7-35.3 against 38.2-40.1 Gpx/s at 64 x 4 (1088 such wavefronts of 26.8 KB of LDS and 176
+    // registers each per launch: two thirds of the chip's LDS for ~11 ms), 42.0 against 44.3 at 128 x 4 (only the 128 tiles as large as
+    // the largest).  profiles/r04_experiments.txt.
     uint32_t jb = 0;
-    if (alpha_side && sel.order && !getenv("XPNG_NO_SPLIT") && !probe_env("XPNG_NO_ENC_SPLIT")) {
+    if (alpha_side && sel.order && probe_env("XPNG_ENC_SPLIT")) {
         const uint32_t nb = (uint64_t)c->n_big * nimg <= 1152 ? c->n_big : ((uint64_t)c->n_top * nimg <= 1152 ? c->n_top : 0u);
         if (nb > 0 && nb < cnt) jb = nb * nimg;
     }
