@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = {4: 10.0, 3: 7.75}  # read PXSZ + chooser re-read PXSZ/4 + write PXSZ+1
-PMC_FILES = {4: "r03_pmc_transform_rgba.json", 3: "r03_pmc_transform_rgb.json"}
+PMC_SUFFIX = {4: "pmc_transform_rgba.json", 3: "pmc_transform_rgb.json"}  # newest profiles/rNN_<suffix>
 
 
 # Environment hygiene.  The release library reads only same-bytes form selectors; every XPNG_* variable
@@ -418,8 +418,8 @@ def roofline_obj(res):
     # HBM bytes per launch of the roofline kernels from the committed PMC passes (FETCH_SIZE doubled + WRITE_SIZE, per pixel):
     # counters cannot be collected inside this run, so the figure is the profile's bytes/px times this launch's pixels
     traffic, traffic_src = None, None
-    for fn in (PMC_FILES[ch], "r01_pmc_transform.json" if ch == 4 else ""):
-        pmc_path = os.path.join(ROOT, "profiles", fn)
+    for pmc_path in (newest_profile(PMC_SUFFIX[ch]),):
+        fn = os.path.basename(pmc_path) if pmc_path else ""
         if fn and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
