@@ -24,17 +24,23 @@ px = 4096 * 4096 * B
 best = {}
 for (k, g) in set(fe) | set(wr):
     if k not in best or g > best[k]: best[k] = g
-rows, tf, tw = [], 0.0, 0.0
+# kernels (or template instances) that only the single-image launches of the bench's verification / latency legs use: the narrow
+# entropy kernels, the 1024-thread walkers, the anti-diagonal reconstruction, xpng_store's normalisation.  They are not part of the
+# batched step (rounds 2-3 counted them: ~0.6 B/px of the 47.5 of profiles/r03_final_pmc_step_mem.json)
+SINGLE = re.compile(r"^k_rans2_encode$|^k_rans2_decode<|^k_dec_recon<|, 1024|<1024>|^k_norm_|^k_any_differs|^k_rans1_encode$|^k_rans1_decode")
+rows, tf, tw, sf, sw = [], 0.0, 0.0, 0.0, 0.0
 for (k, g) in sorted(set(fe) | set(wr)):
     if g * 7 < best[k]: continue         # a single-image launch of the same kernel (the decode tail splits its launches by
     f = fe.get((k, g), 0.0) * 1024 * 2   # tile size class: both parts of such a split are batched launches and count)
     w = wr.get((k, g), 0.0) * 1024       # KiB -> bytes; fetch x2 (gfx950 wide-read correction)
-    tf += f; tw += w
-    rows.append({"kernel": k, "workgroups": g, "fetch_bytes_corrected": int(f), "write_bytes": int(w), "bytes_per_px": round((f + w) / px, 3)})
+    single = bool(SINGLE.search(k))
+    if single: sf += f; sw += w
+    else: tf += f; tw += w
+    rows.append({"kernel": k, "workgroups": g, "fetch_bytes_corrected": int(f), "write_bytes": int(w), "bytes_per_px": round((f + w) / px, 3), **({"single_image_launch": True} if single else {})})
 rows.sort(key=lambda r: -(r["fetch_bytes_corrected"] + r["write_bytes"]))
 pxsz = 3 if rgb else 4
 algo = px * (pxsz + 1.2155) * 2   # encode: read PXSZ + write compressed; decode: read compressed + write PXSZ
 print(json.dumps({"what": f"one encode+decode step over {B} distinct 4096^2 {'RGB' if rgb else 'RGBA'} rasters, one pipeline slot; per-dispatch averages of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)",
                   "pixels_per_step": px, "fetch_bytes_corrected": int(tf), "write_bytes": int(tw), "total_bytes": int(tf + tw),
-                  "bytes_per_px": round((tf + tw) / px, 2), "algorithmic_bytes": int(algo), "algorithmic_bytes_per_px": round(algo / px, 2),
+                  "bytes_per_px": round((tf + tw) / px, 2), "bytes_per_px_with_single_image_launches": round((tf + tw + sf + sw) / px, 2), "algorithmic_bytes": int(algo), "algorithmic_bytes_per_px": round(algo / px, 2),
                   "traffic_over_algorithmic": round((tf + tw) / algo, 2), "kernels": rows}, indent=1))

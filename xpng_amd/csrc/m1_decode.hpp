@@ -42,6 +42,7 @@ struct DecodeWs {
     std::vector<uint64_t> last_off;      // tile offsets already resident in d_off (skip the upload when unchanged)
     uint32_t last_t0 = 0;
     hipStream_t side = nullptr;          // alpha branch runs beside the nl-context branch
+    bool side_borrowed = false;          // `side` is the context's one side stream (the encode's alpha chains use it too, never at the same time): not ours to destroy
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t side2 = nullptr;         // walk / residuals / reconstruction of the smaller tiles, beside the walk of the biggest
     hipEvent_t ev_ctx = nullptr, ev_small = nullptr;
@@ -61,7 +62,7 @@ inline void decode_ws_free(DecodeWs &w) {
     for (void *q : p) if (q) (void)hipFree(q);
     void *planes[] = {w.d_ctxsym, w.d_asym, w.d_alpha, w.d_nlseq, w.d_resid_alloc};
     for (void *q : planes) if (q && !w.planes_in_arena) (void)hipFree(q);
-    if (w.side) (void)hipStreamDestroy(w.side);
+    if (w.side && !w.side_borrowed) (void)hipStreamDestroy(w.side);
     if (w.side2) (void)hipStreamDestroy(w.side2);
     if (w.ev_ctx) (void)hipEventDestroy(w.ev_ctx);
     if (w.ev_small) (void)hipEventDestroy(w.ev_small);
@@ -69,8 +70,10 @@ inline void decode_ws_free(DecodeWs &w) {
     if (w.ev_join) (void)hipEventDestroy(w.ev_join);
     uint8_t *arena = w.arena;
     const uint64_t arena_bytes = w.arena_bytes;
+    hipStream_t lent = w.side_borrowed ? w.side : nullptr;
     w = DecodeWs();  // (also clears last_off)
     w.arena = arena; w.arena_bytes = arena_bytes;
+    if (lent) { w.side = lent; w.side_borrowed = true; }  // (what the context lent stays lent)
 }
 
 // unaligned-safe little-endian u32 load from global memory (tile blobs are only byte-aligned after a raw RGB tile)
@@ -1706,12 +1709,9 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const uint64_t bpr = W * (uint64_t)pxsz;
     uint32_t free_ew, rthreads, rlds;
     recon_geometry(max_w, max_h, free_ew, rthreads, rlds);
-    if (!ws.side) {
-        if (chain_stream_create(&ws.side) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess)
-            return bad("stream/event creation failed");
-    }
+    if (!ws.side && chain_stream_create(&ws.side) != hipSuccess) return bad("stream creation failed");
+    if (!ws.ev_fork && (hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess)) return bad("event creation failed");
     k_dec_parse<<<(total + 63) / 64, 64, 0, s>>>(d_blob_ptrs, ws.d_off, d_blob_len, cnt, total, spt, pxsz, d_tiles, sel, ws.d_info, d_status);
     // Many tiles in flight: instruction issue is the bound, so the rANS chains run 32 streams to a wave (rans2_wide_dec.hpp);
     // few tiles: latency is the bound and a wave per stream (scalar cursors, hot-symbol registers) is quicker.

@@ -314,11 +314,9 @@ inline int m2_wide_decode(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint32_t t
     const uint32_t groups = (total + 31) / 32;
     k_rans1_dec_prep<<<total * 18, 64, 0, s>>>(d_info2, d_tiles, sel, d_blk2, d_tabs2, d_scratch2, d_sbase2, d_stream_n2, ws.d_wdec2, ws.d_dtab2);
     // the two chain launches are independent: the big-alphabet slots run on the side stream beside the small ones
-    if (!ws.side) {
-        if (chain_stream_create(&ws.side) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess) { err = "stream/event creation failed"; return 1; }
-    }
+    if (!ws.side && chain_stream_create(&ws.side) != hipSuccess) { err = "stream creation failed"; return 1; }
+    if (!ws.ev_fork && (hipEventCreateWithFlags(&ws.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming) != hipSuccess)) { err = "event creation failed"; return 1; }
     if (hipEventRecord(ws.ev_fork, s) != hipSuccess || hipStreamWaitEvent(ws.side, ws.ev_fork, 0) != hipSuccess) { err = "fork failed"; return 1; }
     k_rans1_dec_chain<true><<<groups * 7, 64, Dec1ChainLds<true>::BYTES, ws.side>>>(d_info2, total, ws.d_wdec2, ws.d_dtab2, d_scratch2);
     if (hipEventRecord(ws.ev_join, ws.side) != hipSuccess) { err = "join record failed"; return 1; }

@@ -130,7 +130,10 @@ struct xpnghip_ctx {
     // decode keeps its own pair of tables: a caller that alternates encode and decode on one context (a pipeline) would
     // otherwise re-upload, and synchronise its stream, on every call
     uint32_t *d_order = nullptr;          // tile indices of [r0, r1) by decreasing pixel count (TileSel::order)
-    hipStream_t enc_side = nullptr;       // the alpha chains of a batched encode run beside the context chains
+    // ONE side stream per context [r4]: the alpha chains of a batched encode run on it beside the context chains, and the alpha branch
+    // of a decode (DecodeWs::side borrows it) - never at the same time, the calls on a context are ordered.  Every stream alive takes
+    // a hardware queue, and the chip runs ~16-20 of them side by side before the pipeline slots start to cost each other (r04_experiments)
+    hipStream_t enc_side = nullptr;
     hipEvent_t ev_enc_fork = nullptr, ev_enc_join = nullptr;
     const uint8_t **d_dec_in_ptrs = nullptr;
     uint8_t **d_dec_out_ptrs = nullptr;
@@ -453,8 +456,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
                  c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wF, c->h_total);
     const uint8_t *planesA = c->d_planes;
     const bool alpha_side = !narrow && PXSZ == 4;
-    if (alpha_side && !c->enc_side) {
-        HIPCHK(chain_stream_create(&c->enc_side));
+    if (alpha_side && !c->enc_side) HIPCHK(chain_stream_create(&c->enc_side));
+    if (alpha_side && !c->ev_enc_fork) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_enc_join, hipEventDisableTiming));
     }
@@ -621,6 +624,10 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
     uint32_t max_w = 0, max_h = 0, min_w = ~0u;
     for (uint64_t i = t0; i < t1; i++) { max_w = c->tiles[i].w > max_w ? c->tiles[i].w : max_w; max_h = c->tiles[i].h > max_h ? c->tiles[i].h : max_h; min_w = c->tiles[i].w < min_w ? c->tiles[i].w : min_w; }
     if (ensure_arena(c)) return 1;
+    if (!c->dec.side) {  // (also after decode_ws_prepare rebuilt the workspace: it forgets the loan)
+        if (!c->enc_side) HIPCHK(chain_stream_create(&c->enc_side));
+        c->dec.side = c->enc_side; c->dec.side_borrowed = true;
+    }
     XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles, c->dec.arena);
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
