@@ -374,10 +374,9 @@ def test_batch_kernels_forced_on_small_inputs(gpu, manifest, po, tmp_path, monke
 def test_large_batch_takes_the_wide_path_and_matches(gpu, po, monkeypatch, alpha, split):
     """A batch big enough to select the wide kernels by itself (tiles x streams > 2048); RGBA and RGB (the one-wave-per-tile
     band reconstruction writes 16-byte and 12-byte pixel groups respectively); with and without the decode tail split by tile
-    size class (XPNG_SPLIT=1: the library takes it by itself only when GPU_MAX_HW_QUEUES >= 24)."""
-    if split:
-        monkeypatch.setenv("XPNG_SPLIT", "1")
-    else:
+    size class (the default since round 4: the big-tile class on the side stream behind the alpha chains, the small-tile class on
+    the caller's stream; XPNG_NO_SPLIT=1: one walk, one tail)."""
+    if not split:
         monkeypatch.setenv("XPNG_NO_SPLIT", "1")
     import torch
     from xpng_amd.api import walk_tile_offsets

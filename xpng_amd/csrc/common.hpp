@@ -10,9 +10,9 @@
 namespace xpng {
 
 // ---- build flavours ---------------------------------------------------------------------------------------------------
-// The release library (libxpng_hip.so) reads exactly these six environment variables, each of which selects between forms that
+// The release library (libxpng_hip.so) reads exactly these five environment variables, each of which selects between forms that
 // produce the SAME bytes (INTEGRATION.md lists them): XPNG_DEVICE, XPNG_GPUS, XPNG_WIDE_RANS, XPNG_NARROW_RANS,
-// XPNG_SPLIT, XPNG_NO_SPLIT (and the runtime's own GPU_MAX_HW_QUEUES).  Everything that exists for timing
+// XPNG_NO_SPLIT (it also WRITES the runtime's GPU_MAX_HW_QUEUES when it is loaded, unless the caller has set it).  Everything that exists for timing
 // studies - kernel knock-outs, unused-LDS pads, no-store switches, phase stamps, the wave probe, stream priorities, fake
 // devices - is compiled only into libxpng_hip_probes.so (-DXPNG_PROBES, `make probes`; tools/ load that one): a product
 // library whose output can be falsified through the environment is not shippable.
@@ -21,7 +21,6 @@ inline const char *probe_env(const char *name) { return getenv(name); }
 #else
 inline const char *probe_env(const char *) { return nullptr; }
 #endif
-int user_hw_queues();  // GPU_MAX_HW_QUEUES as the CALLER exported it (0: not at all); xpng_hip.hip
 inline size_t probe_pad(const char *name) { const char *v = probe_env(name); return v ? (size_t)atoi(v) : 0; }  // bytes of unused dynamic LDS (occupancy throttle)
 
 // Streams that carry serial-chain kernels.  tools/wave_probe.py shows that in the pipelined bench the chain WAVES run at their solo

@@ -1742,18 +1742,17 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
         k_rans2_decode<15><<<total * 9, 64, 0, s>>>(ws.d_info, d_tiles, sel, 0, 9, 1, ws.d_ctxsym, ws.d_asym, dbg);  // blocks with PROB_BITS > 12 only
     }
     // Two size classes: the walk's duration is the chain of the biggest tile, and the work enumeration is sorted by size, so the
-    // first n_big tiles of the order (x B images) are walked on `s` while the rest - shorter chains - are walked on a second
-    // stream, which then extracts residuals and reconstructs them while the big walk is still running; what is left behind
-    // the long walk is the residual / reconstruction work of the few big tiles only.
+    // first n_big tiles of the order (x B images) are walked beside the rest - shorter chains, the lane-per-tile form - and each
+    // class goes on to its own residual extraction and reconstruction: what is left behind the longer walk is the tail of ITS tiles only.
+    // [r4] On TWO streams: the small-tile class stays on the caller's stream behind the context chains; the big-tile class runs on the
+    // side stream BEHIND the alpha chains (its walk, ~14 ms, starts ~13 ms later than it could and still ends before the small tiles'
+    // walk, ~28 ms, does).  Rounds 2-3 gave the small-tile class a third stream: every stream alive is a hardware queue, and with
+    // 4 streams per context the fifth and sixth pipeline slot LOST throughput (36 / 33 against 38.5 Gpx/s); with one side stream for
+    // the encode's and the decode's alpha branch and no third stream, 64 x 6 reads 43 where 64 x 4 reads 39 (profiles/r04_experiments.txt).
+    // (probe builds: XPNG_SPLIT3=1 = the three-stream form.)
     const bool band = wide && max_w <= RB_MAXW && !probe_env("XPNG_WAVEFRONT_RECON");
-    // (a third stream per context: with fewer hardware queues than the streams of all contexts in flight, streams share a queue
-    // and serialise - measured 31 -> 21 Gpx/s at 4 contexts and 16 queues - so the split is taken only when the CALLER asked
-    // the runtime for at least 24 queues, GPU_MAX_HW_QUEUES, as bench.py does, or asks for the split outright (XPNG_SPLIT).  The
-    // default the library writes into the environment when it is loaded does not count: if HIP was initialised before the load,
-    // the runtime never saw it)
-    static const bool many_queues = user_hw_queues() >= 24;
-    const bool split = band && d_order && n_big > 0 && n_big < cnt && !probe_env("XPNG_NARROW_WALK") && !getenv("XPNG_NO_SPLIT") &&
-                       (many_queues || getenv("XPNG_SPLIT"));
+    const bool split = band && d_order && n_big > 0 && n_big < cnt && !probe_env("XPNG_NARROW_WALK") && !getenv("XPNG_NO_SPLIT");
+    const bool split3 = split && probe_env("XPNG_SPLIT3");
     const uint32_t jb = split ? n_big * B : 0;
     const uint32_t nostore = probe_env("XPNG_DBG_NOSTORE") ? 1u : 0u;
     // Occupancy limiter of the band reconstruction: 12 KB of unused LDS per wave keep it at ~10 waves per CU.  Its scattered
@@ -1763,54 +1762,62 @@ inline int decode_m1_launch(DecodeWs &ws, uint32_t B, uint64_t n_tiles, uint64_t
     const size_t dbg_pad = probe_pad("XPNG_RECON_LDS_PAD");
     const size_t pad_rs = probe_pad("XPNG_PAD_RS");
     const uint32_t lpw = probe_env("XPNG_WALK_LPW") ? (uint32_t)atoi(probe_env("XPNG_WALK_LPW")) : 64u;  // tiles per wavefront of the small-tile walk: 64, or (probe builds) 32 / 16 - the same bytes
+    // ts / tb: the streams the small-tile and the big-tile tails run on
+    hipStream_t ts = s, tb = s;
     if (split) {
-        if (!ws.side2) {
-            if (chain_stream_create(&ws.side2) != hipSuccess ||
-                hipEventCreateWithFlags(&ws.ev_ctx, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming) != hipSuccess)
-                return bad("stream/event creation failed");
-        }
-        if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(ws.side2, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
+        if (!ws.ev_ctx && (hipEventCreateWithFlags(&ws.ev_ctx, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming) != hipSuccess)) return bad("event creation failed");
+        if (split3) {
+            if (!ws.side2 && chain_stream_create(&ws.side2) != hipSuccess) return bad("stream creation failed");
+            ts = ws.side2;
+        } else tb = ws.side;
+        hipStream_t other = split3 ? ts : tb;  // the stream that is not `s`: it starts behind the context chains
+        if (hipEventRecord(ws.ev_ctx, s) != hipSuccess || hipStreamWaitEvent(other, ws.ev_ctx, 0) != hipSuccess) return bad("fork failed");
         if (!dbg_skip("walk_small")) {
-            if (lpw == 32) k_dec_walk_wide<32><<<(total - jb + 31) / 32, 64, WALK_WIDE_LDS_BYTES(32) + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
-            else if (lpw == 16) k_dec_walk_wide<16><<<(total - jb + 15) / 16, 64, WALK_WIDE_LDS_BYTES(16) + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
-            else k_dec_walk_wide<64><<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64) + pad_ch + probe_pad("XPNG_PAD_WALK"), ws.side2>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+            if (lpw == 32) k_dec_walk_wide<32><<<(total - jb + 31) / 32, 64, WALK_WIDE_LDS_BYTES(32) + pad_ch + probe_pad("XPNG_PAD_WALK"), ts>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+            else if (lpw == 16) k_dec_walk_wide<16><<<(total - jb + 15) / 16, 64, WALK_WIDE_LDS_BYTES(16) + pad_ch + probe_pad("XPNG_PAD_WALK"), ts>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
+            else k_dec_walk_wide<64><<<(total - jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64) + pad_ch + probe_pad("XPNG_PAD_WALK"), ts>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, jb);
         }
         // the biggest tiles' chains are the longest of the decode: they get the scalar-unit walk, one wave per tile (~40 ns per
         // step against ~95 for the lane-per-tile form; a few waves per CU, so the CU's one scalar ALU is not contended), while
         // the many smaller tiles keep the lane-per-tile form beside them (XPNG_WIDE_BIG_WALK=1: the old form for both)
-        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<64><<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64), s>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
-        else k_dec_walk<<<jb, 64, pad_ch, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
-        if (pxsz == 4 && hipStreamWaitEvent(ws.side2, ws.ev_join, 0) != hipSuccess) return bad("join failed");
+        if (dbg_skip("walk_big")) {} else if (probe_env("XPNG_WIDE_BIG_WALK")) k_dec_walk_wide<64><<<(jb + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64), tb>>>(ws.d_info, d_tiles, sel, jb, ws.d_ctxsym, ws.d_nlseq, 0);
+        else k_dec_walk<<<jb, 64, pad_ch, tb>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
+        // (RGBA: the alpha symbols are complete at ev_join, recorded on the side stream right behind the alpha chains - in front of the
+        //  big-tile walk when that runs there)
+        if (pxsz == 4 && ts != ws.side && hipStreamWaitEvent(ts, ws.ev_join, 0) != hipSuccess) return bad("join failed");
         if (pxsz == 4) {
-            if (dbg_skip("resid_small")) {} else if (fold) k_dec_resid<4, 256, true><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
-            else k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
-            if (!dbg_skip("recon_small")) k_dec_recon_band<4><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb, total);
+            if (dbg_skip("resid_small")) {} else if (fold) k_dec_resid<4, 256, true><<<total - jb, 256, pad_rs, ts>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
+            else k_dec_resid<4, 256><<<total - jb, 256, pad_rs, ts>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
+            if (!dbg_skip("recon_small")) k_dec_recon_band<4><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ts>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, jb, total);
         } else {
-            k_dec_resid<3, 256><<<total - jb, 256, 0, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
-            k_dec_recon_band<3><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ws.side2>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb, total);
+            k_dec_resid<3, 256><<<total - jb, 256, 0, ts>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, jb);
+            k_dec_recon_band<3><<<recon_grid(total - jb), 64, RB_LDS_BYTES(max_w) + dbg_pad, ts>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, jb, total);
         }
-        if (hipEventRecord(ws.ev_small, ws.side2) != hipSuccess) return bad("join record failed");
     } else if (wide && !probe_env("XPNG_NARROW_WALK")) k_dec_walk_wide<64><<<(total + 63) / 64, 64, WALK_WIDE_LDS_BYTES(64), s>>>(ws.d_info, d_tiles, sel, total, ws.d_ctxsym, ws.d_nlseq, 0);
     else k_dec_walk<<<total, 64, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_ctxsym, ws.d_nlseq);
-    const uint32_t nt = split ? jb : total;  // work items [0, nt) are still to be finished on `s`
-    if (pxsz == 4 && hipStreamWaitEvent(s, ws.ev_join, 0) != hipSuccess) return bad("join failed");
+    const uint32_t nt = split ? jb : total;  // work items [0, nt): the big-tile class of a split decode (on tb), or everything (on s)
+    if (pxsz == 4 && tb != ws.side && hipStreamWaitEvent(tb, ws.ev_join, 0) != hipSuccess) return bad("join failed");
     if (pxsz == 4) {
-        if (dbg_skip("resid_big")) {} else if (wide && fold) k_dec_resid<4, 256, true><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
-        else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
-        else if (fold) k_dec_resid<4, 1024, true><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
-        else k_dec_resid<4, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
-        if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0, nt);
-        else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
-        else k_dec_recon<4><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
+        if (dbg_skip("resid_big")) {} else if (wide && fold) k_dec_resid<4, 256, true><<<nt, 256, pad_rs, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else if (wide) k_dec_resid<4, 256><<<nt, 256, pad_rs, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else if (fold) k_dec_resid<4, 1024, true><<<nt, 1024, 0, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else k_dec_resid<4, 1024><<<nt, 1024, 0, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        if (dbg_skip("recon_big")) {} else if (band) k_dec_recon_band<4><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, tb>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, nostore, 0, nt);
+        else if (free_ew) k_dec_recon<4><<<total, rthreads, rlds, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+        else k_dec_recon<4><<<total, 1024, 0, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     } else {
-        if (wide) k_dec_resid<3, 256><<<nt, 256, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
-        else k_dec_resid<3, 1024><<<nt, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
-        if (band) k_dec_recon_band<3><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, s>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0, nt);
-        else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
-        else k_dec_recon<3><<<total, 1024, 0, s>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
+        if (wide) k_dec_resid<3, 256><<<nt, 256, 0, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        else k_dec_resid<3, 1024><<<nt, 1024, 0, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_asym, ws.d_nlseq, ws.d_resid, 0);
+        if (band) k_dec_recon_band<3><<<recon_grid(nt), 64, RB_LDS_BYTES(max_w) + dbg_pad, tb>>>(ws.d_info, d_tiles, sel, ws.d_resid, d_raster_ptrs, bpr, 0u, 0, nt);
+        else if (free_ew) k_dec_recon<3><<<total, rthreads, rlds, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, free_ew);
+        else k_dec_recon<3><<<total, 1024, 0, tb>>>(ws.d_info, d_tiles, sel, ws.d_alpha, ws.d_resid, d_raster_ptrs, bpr, 0);
     }
-    if (split && hipStreamWaitEvent(s, ws.ev_small, 0) != hipSuccess) return bad("join failed");
+    // everything rejoins the caller's stream: the stream that is not `s` hands in its tail's end
+    if (split) {
+        hipStream_t other = split3 ? ts : tb;
+        if (hipEventRecord(ws.ev_small, other) != hipSuccess || hipStreamWaitEvent(s, ws.ev_small, 0) != hipSuccess) return bad("join failed");
+    }
     if (hipGetLastError() != hipSuccess) return bad("decode kernel launch failed");
     return 0;
 }

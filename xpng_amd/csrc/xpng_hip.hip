@@ -49,19 +49,13 @@ static int fail(const std::string &m) { g_err = m; return 1; }
             if (!q_) return fail("internal error: a workspace buffer of this launch sequence was never allocated (one of: " #__VA_ARGS__ ")"); \
     } while (0)
 
-// A batched decode forks three streams per context and a pipelined caller keeps several contexts in flight: with the runtime's
-// default of 4 hardware queues those streams share queues and serialise (measured: 31 -> 21 Gpx/s).  The runtime reads
-// GPU_MAX_HW_QUEUES when it initialises - the first HIP call of the process - so the library asks for 32 when it is LOADED,
-// unless the caller has chosen a value.  A process that has already initialised HIP before loading this library keeps what it
-// had (export the variable yourself in that case: INTEGRATION.md) - which is why nothing in the library may conclude from the
-// variable's value that the queues exist unless the CALLER put it there: g_user_hw_queues is what the caller exported (0 = nothing),
-// taken before the library writes its own default.
-static int g_user_hw_queues = 0;
-__attribute__((constructor)) static void xpnghip_on_load(void) {
-    if (const char *q = getenv("GPU_MAX_HW_QUEUES")) g_user_hw_queues = atoi(q);
-    (void)setenv("GPU_MAX_HW_QUEUES", "32", 0);
-}
-namespace xpng { int user_hw_queues() { return g_user_hw_queues; } }
+// A context forks a side stream and a pipelined caller keeps several contexts in flight: with the runtime's default of 4 hardware
+// queues those streams share queues and serialise (measured: 31 -> 21 Gpx/s).  The runtime reads GPU_MAX_HW_QUEUES when it
+// initialises - the first HIP call of the process - so the library asks for 32 when it is LOADED, unless the caller has chosen a
+// value.  A process that has already initialised HIP before loading this library keeps what it had (export the variable yourself in
+// that case: INTEGRATION.md).  Nothing in the library reads the variable back: no code path depends on the queues being there
+// (round 3's decode took a third stream per context when it saw >= 24 here - ADVICE r3; the split needs no third stream any more).
+__attribute__((constructor)) static void xpnghip_on_load(void) { (void)setenv("GPU_MAX_HW_QUEUES", "32", 0); }
 
 extern "C" int xpnghip_abi_version(void) { return XPNGHIP_ABI_VERSION; }
 extern "C" const char *xpnghip_last_error(void) { return g_err.c_str(); }
