@@ -450,11 +450,11 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the RGB legs of config 3")
     ap.add_argument("--no-config4", action="store_true", help="skip the 16384^2 strong-scaling leg")
     ap.add_argument("--roofline-reps", type=int, default=50)
-    ap.add_argument("--pipeline", type=int, default=4,
+    ap.add_argument("--pipeline", type=int, default=8,
                     help="contexts (each with its own HIP stream and buffers) that consecutive steps alternate between, so the "
                          "encode of step k+1 runs beside the decode of step k; 1 = strictly serial steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo moves blobs through the host, for rehearsals)")
-    ap.add_argument("--batch", type=int, default=128,
+    ap.add_argument("--batch", type=int, default=64,
                     help="images per launch per rank: a step encodes+decodes `batch` rasters of the workload in one batched launch "
                          "sequence (the entropy stage is a serial chain per tile stream, so one image alone cannot fill 256 CUs)")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="experiment: host sleep between the first steps of the pipeline slots (warm-up), so that their cycles start apart; 0 = off")
@@ -508,8 +508,8 @@ def main():
         # memory and a down-clocked part, and its bandwidth-bound roofline pair reads 0.31-0.36 instead of the 0.55 of a clean run
         env.torch.cuda.empty_cache()
         for name, lvl in (("rgb_l1", 1), ("rgb_l2", 2)):
-            # (level 2 holds 27 B/px of workspace against level 1's 12: 96 rasters per launch instead of 128 keep it at ~213 GB)
-            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 128 if lvl == 1 else 96)), "--pipeline", str(min(P, 4)),
+            # (level 2 holds 27 B/px of workspace against level 1's 12: three quarters of the rasters per launch keep it at ~213 GB)
+            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 128) if lvl == 1 else max(1, min(B, 128) * 3 // 4)), "--pipeline", str(min(P, 8)),
                    "--steps", str(max(6, args.steps // 3)), "--warmup", "2", "--roofline-reps", str(max(10, args.roofline_reps // 2)), "--no-legs", "--no-config4"]
             if args.no_cpu:
                 cmd.append("--no-cpu")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# headline leg only (64 rasters x 4 slots), N runs; prints value / ms_per_step / single-image times.  usage: quick_bench.sh [N] [extra bench args]
+# headline leg only (default batch x slots), N runs; prints value / ms_per_step / single-image times.  usage: quick_bench.sh [N] [extra bench args]
 n=${1:-2}; shift
 for i in $(seq $n); do
   python bench.py --no-legs --no-config4 --no-cpu --steps 20 --warmup 5 --roofline-reps 20 "$@" 2>/dev/null | python3 -c "
