@@ -575,7 +575,8 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic '{args.kind}' {'RGBA8' if alpha else 'RGB8'}, level -{args.level} ({'FAST' if args.level == 1 else 'SLOW'}), tile encode + decode "
-                                   f"(tile-size walk included), rasters and blobs resident in HBM; batch throughput: {B} distinct rasters per launch x {r['P']} pipelined contexts",
+                                   f"(tile-size walk included), rasters (already normalised: normalize_RGBA is part of single_image.store_ms, not of the pipelined step) and blobs resident in HBM; "
+                                   f"batch throughput: {B} distinct rasters per launch x {r['P']} pipelined contexts",
                        "batch": B, "pipeline_slots": r["P"], "tiles": r["tiles"], "tiles_per_rank": r["tiles_per_rank"], "share_px": r["my_px"],
                        "parallelism": f"tile-range x{world}" + (f" + file assembly spread over the ranks (image b on rank b % {world}): one packed message per rank pair and step ({'RCCL send/recv over xGMI' if args.backend == 'nccl' else args.backend})" if world > 1 else ""),
                        "compressed_bytes": r["compressed_bytes"], "distinct_rasters_per_launch": B,
