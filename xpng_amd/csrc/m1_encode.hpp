@@ -694,8 +694,11 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
 // Outputs: ctx streams (their lengths and places are known beforehand: k_m1_lens), k words + count.   grid = tiles, block = 1024.
 // THREADS = 1024 for a few tiles (shortest serial walk per tile); 256 for large batches: the chain kernels of other
 // batches in flight leave few CUs with room for a 16-wave workgroup, but almost all have room for a 4-wave one.
+#ifndef XPNG_ST_WAVES
+#define XPNG_ST_WAVES 0   // waves per SIMD the routing kernel is compiled for (0: whatever its registers allow - 6)
+#endif
 template <int PXSZ, int ST_THREADS>
-__global__ __launch_bounds__(ST_THREADS) void k_m1_streams(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
+__global__ __launch_bounds__(ST_THREADS, (XPNG_ST_WAVES && ST_THREADS == 256) ? XPNG_ST_WAVES : 1) void k_m1_streams(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                            const TileDesc *__restrict__ tiles, TileSel sel,
                                                            const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                            uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
