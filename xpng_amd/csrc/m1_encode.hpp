@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
     if (nlh) nlacc_commit<256>(hacc, s_red, nlh + ((uint64_t)tile * nlh_slots + chunk) * NLH_STRIDE);  // (nlh is a kernel argument: the whole workgroup takes the same side)
 }
 
-constexpr uint32_t TR_ROWS = 8, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
+#ifndef XPNG_TR_ROWS
+#define XPNG_TR_ROWS 8
+#endif
+constexpr uint32_t TR_ROWS = XPNG_TR_ROWS, TR_MAXW = 672, TR_PITCH = TR_MAXW * 4 + 32;  // bytes per LDS row (16-byte multiple)
 static_assert((TR_ROWS * TR_MAXW / 4 + 255) / 256 <= 7 && TG_REPS <= 7, "NlAcc: a thread's groups per workgroup must fit its 3-bit fields");
 __host__ __device__ inline uint32_t nlh_records(uint32_t w, uint32_t h, bool generic) {
     return generic ? (w * h + 1024u * TG_REPS - 1) / (1024u * TG_REPS) : (h + TR_ROWS - 1) / TR_ROWS;
