@@ -4,7 +4,7 @@ verification) once per kernel with that kernel left unlaunched (XPNG_SKIP, csrc/
 identical results, so everything downstream still works on valid data) and prints the step time beside the full pipeline's.
 The difference is the kernel's marginal cost where it matters - isolated durations say little about a pipeline in which
 latency-bound chains and bandwidth kernels of several slots overlap.
-usage: knockout.py [P=5] [B=64] [mode=both|enc|dec] [names,comma,separated | all]          (child: knockout.py --child ...)"""
+usage: knockout.py [P=5] [B=64] [mode=both|enc|dec] [names,comma,separated (a+b = both together) | all]          (child: knockout.py --child ...)"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ["chooser", "transform", "streams", "prep_a", "chain_a", "prep_c", "chain_c", "finish", "gather",
@@ -63,7 +63,9 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 mode = sys.argv[3] if len(sys.argv) > 3 else "both"
 sel = sys.argv[4] if len(sys.argv) > 4 else "all"
-cases = [("none", "")] + ([(n, n) for n in NAMES] + list(GROUPS.items()) if sel == "all" else [(n, GROUPS.get(n, n)) for n in sel.split(",")])
+def expand(case):  # "all_bw+chain_a": several names or groups knocked out together
+    return ",".join(GROUPS.get(n, n) for n in case.split("+"))
+cases = [("none", "")] + ([(n, n) for n in NAMES] + list(GROUPS.items()) if sel == "all" else [(n, expand(n)) for n in sel.split(",")])
 base = None
 for name, skip in cases:
     env = dict(os.environ, XPNG_SKIP=skip or "nothing", XPNG_SKIP_AFTER=str(4 * P))
@@ -74,4 +76,4 @@ for name, skip in cases:
         print(name, "FAILED", r.stderr[-300:], flush=True)
         continue
     if base is None: base = ms
-    print(f"{name:12s} {ms:8.2f} ms/step   saves {base - ms:6.2f} ms ({(base - ms) / base * 100:5.1f} %)", flush=True)
+    print(f"{name:24s} {ms:8.2f} ms/step   saves {base - ms:6.2f} ms ({(base - ms) / base * 100:5.1f} %)", flush=True)

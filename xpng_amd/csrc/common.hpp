@@ -119,6 +119,16 @@ constexpr bool dbg_skip(const char *) { return false; }
 #ifndef XPNG_CHAIN_PRIO
 #define XPNG_CHAIN_PRIO 3
 #endif
+// wave priority of the chip-filling (throughput) kernels of the batched paths, set by their first instruction (r4 experiment:
+// with everything at 0 the issue arbiter serves the OLDEST wave first, i.e. the long-lived chain waves, just as with the chains at 3)
+#ifndef XPNG_BW_PRIO
+#define XPNG_BW_PRIO 0
+#endif
+__device__ __forceinline__ void bw_prio() {
+#if XPNG_BW_PRIO
+    __builtin_amdgcn_s_setprio(XPNG_BW_PRIO);
+#endif
+}
 constexpr uint32_t TILE_AREA = 444u * 444u;  // reference libxpng.c:49
 constexpr uint32_t NL_NONE = 0xFFu;          // nl-plane marker: pixel emits no colour symbol
 constexpr int WAVE = 64;

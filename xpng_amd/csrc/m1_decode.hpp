@@ -112,6 +112,7 @@ __global__ void k_dec_parse(const uint8_t *const *__restrict__ blobs, const uint
                             const uint64_t *__restrict__ blob_len, uint32_t cnt, uint32_t total, uint32_t spt, int pxsz,
                             const TileDesc *__restrict__ tiles, TileSel sel, DecTile *__restrict__ info,
                             uint32_t *__restrict__ status) {
+    bw_prio();
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
     const uint32_t vt = vtile(sel, j), il = imglin(sel, vt);  // off[] is image-major (host order)
@@ -999,6 +1000,7 @@ __global__ __launch_bounds__(THREADS) void k_dec_resid(const DecTile *__restrict
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     uint8_t *__restrict__ alpha, const uint8_t *__restrict__ asym, const uint8_t *__restrict__ nlseq,
                                                     uint32_t *__restrict__ resid, uint32_t j0) {
+    bw_prio();
     static_assert(!FOLD || PXSZ == 4, "only RGBA tiles carry alpha");
     // One workgroup walks a tile in raster order, THREADS * 4 pixels per iteration; a lane owns 4 consecutive pixels: one
     // dword of the alpha plane (read one iteration ahead), up to 4 consecutive nl symbols, up to 96 bits of k, one 16-byte
@@ -1346,6 +1348,7 @@ __global__ __launch_bounds__(1024) void k_dec_recon(const DecTile *__restrict__ 
                                                     const TileDesc *__restrict__ tiles, TileSel sel,
                                                     const uint8_t *__restrict__ alpha, const uint32_t *__restrict__ resid,
                                                     uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t free_ew) {
+    bw_prio();
     const uint32_t j = blockIdx.x, tid = threadIdx.x;
     const DecTile d = info[j];
     const TileDesc t = tiles[vtile(sel, j)];
@@ -1579,6 +1582,7 @@ template <int PXSZ>
 __global__ __launch_bounds__(64) void k_dec_recon_band(const DecTile *__restrict__ info, const TileDesc *__restrict__ tiles,
                                                        TileSel sel, const uint32_t *__restrict__ resid,
                                                        uint8_t *const *__restrict__ rasters, uint64_t bpr, uint32_t dbgflags, uint32_t j0, uint32_t j1) {
+    bw_prio();
     extern __shared__ uint32_t rb_lds[];  // the lanes' staging rings, then one row of the widest tile of the launch (bottom row of the band above)
     uint32_t *seam = rb_lds + RB_STAGE_WORDS;
     const uint32_t lane = threadIdx.x & 63;

@@ -22,6 +22,7 @@ template <int PXSZ>
 __global__ __launch_bounds__(256) void k_chooser(const uint8_t *const *__restrict__ rasters, uint64_t bpr,
                                                  const TileDesc *__restrict__ tiles, TileSel sel, uint32_t strips,
                                                  uint32_t *__restrict__ sums) {
+    bw_prio();
     const uint32_t tile = vtile(sel, blockIdx.x / strips), strip = blockIdx.x % strips;
     const TileDesc t = tiles[tile];
     const uint8_t *__restrict__ raster = rasters[t.img];
@@ -275,6 +276,7 @@ __host__ __device__ inline uint32_t nlh_records(uint32_t w, uint32_t h, bool gen
 // grid = tiles, block = 64.
 __global__ __launch_bounds__(64) void k_m1_lens(const uint32_t *__restrict__ nlh, uint32_t slots, uint32_t generic, const TileDesc *__restrict__ tiles,
                                                 TileSel sel, uint32_t *__restrict__ ctx_n) {
+    bw_prio();
     const uint32_t tile = vtile(sel, blockIdx.x), lane = threadIdx.x & 63;
     const TileDesc t = tiles[tile];
     uint32_t h[10];
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_generic(const uint8_t *con
                                                               const TileDesc *__restrict__ tiles, TileSel sel,
                                                               uint32_t blocks_per_tile, const uint32_t *__restrict__ sums,
                                                               uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t *__restrict__ nlh, uint32_t nlh_slots) {
+    bw_prio();
     __shared__ uint32_t s_red[4][6];
     NlAcc hacc = nlacc_zero();
     const uint32_t tile = vtile(sel, blockIdx.x / blocks_per_tile), chunk = blockIdx.x % blocks_per_tile;
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgba(const uint8_t *const 
                                                            uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
                                                            uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks,
                                                            uint32_t *__restrict__ nlh, uint32_t nlh_slots) {
+    bw_prio();
     __shared__ __align__(16) uint8_t rows[(TR_ROWS + 1) * TR_PITCH];
     __shared__ uint32_t s_red[4][6];
     // Consecutive block ids round-robin over the 8 XCDs, each with its own L2; consecutive strips of a tile share a halo row.
@@ -636,6 +640,7 @@ __global__ __launch_bounds__(256) void k_m1_transform_rgb(const uint8_t *const *
                                                           uint32_t strips_per_tile, const uint32_t *__restrict__ sums,
                                                           uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t nblocks,
                                                           uint32_t *__restrict__ nlh, uint32_t nlh_slots) {
+    bw_prio();
     __shared__ __align__(16) uint8_t rows[TR3_LDS_PAD + (TR_ROWS + 1) * TR_PITCH + 16];
     __shared__ uint32_t s_red[4][6];
     const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware: consecutive strips of a tile on one XCD
@@ -706,6 +711,7 @@ __global__ __launch_bounds__(ST_THREADS, (XPNG_ST_WAVES && ST_THREADS == 256) ? 
                                                            const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                            uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                            uint32_t *__restrict__ k_n) {
+    bw_prio();
     // One workgroup walks a tile in raster order, ST_THREADS * 4 pixels per iteration: a lane owns 4 consecutive pixels
     // (one dword of each plane).  Per iteration: the previous-coded-nl chain (pl), a packed prefix sum of the nine
     // per-context counts (three 10-bit fields per word, three DPP scans), one scan of the bit lengths, byte stores into the

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                    uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
                                                    uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF, uint32_t j0) {
+    bw_prio();
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
     __shared__ EncSym tab[256];
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(64) void k_rans2_finish(const TileDesc *__restrict_
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                      uint32_t *__restrict__ blk_sz, const WPrep *__restrict__ prep,
                                                      const uint16_t *__restrict__ wF) {
+    bw_prio();
     const uint32_t tile = vtile(sel, blockIdx.x / spt), c = blockIdx.x % spt, lane = threadIdx.x & 63;
     const WPrep p = prep[(uint64_t)tile * 10 + c];
     if (p.kind != 1) return;

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_prep(const DecTile *__restrict
                                                        TileSel sel, uint32_t spt, uint8_t *__restrict__ ctxsym,
                                                        uint8_t *__restrict__ asym, WDec *__restrict__ wdec,
                                                        uint8_t *__restrict__ dtab) {
+    bw_prio();
     __shared__ uint32_t fc[256];
     __shared__ uint32_t Fs[260];
     const uint32_t j = blockIdx.x / spt, c = blockIdx.x % spt, lane = threadIdx.x & 63;

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_tile_gather(const uint8_t *const *__res
                                                      const uint32_t *__restrict__ ctx_n,
                                                      const uint32_t *__restrict__ blk_sz, const uint32_t *__restrict__ tile_hdr,
                                                      const uint64_t *__restrict__ off, uint8_t *const *__restrict__ blobs) {
+    bw_prio();
     const uint32_t j = blockIdx.x, tile = vtile(sel, j);
     const TileDesc t = tiles[tile];
     const uint8_t *__restrict__ raster = rasters[t.img];
