@@ -57,6 +57,11 @@ cuid = ((xcc.astype(np.int64) * 8 + se) * 2 + sh) * 16 + cu
 simdid = cuid * 4 + simd
 print("distinct CUs seen", len(np.unique(cuid)), "distinct SIMDs", len(np.unique(simdid)), "xcc values", np.unique(xcc), "se", np.unique(se), "sh", np.unique(sh), "cu", np.unique(cu))
 dur = (rec["t1"] - rec["t0"]).astype(np.float64) / 100e3  # ms
+cyc = (rec["xcc"] >> 4).astype(np.float64) * 16.0      # shader-clock cycles of the wave (s_memtime)
+long_ = dur > 5
+if long_.any():
+    mhz = cyc[long_] / (dur[long_] * 1e3)
+    print(f"shader clock over the waves longer than 5 ms: p10 {np.percentile(mhz,10):.0f} median {np.median(mhz):.0f} p90 {np.percentile(mhz,90):.0f} MHz")
 names = {1: "chain2<ctx>", 2: "chain2<alpha>", 3: "dec_chain<ctx>", 4: "dec_chain<alpha>", 5: "walk_wide", 6: "walk(SALU)"}
 # co-residency: time-weighted number of other probed waves on the same SIMD / CU
 order = np.argsort(rec["t0"])
@@ -102,3 +107,16 @@ for k in sorted(names):
     for lo, hi in ((0, 0.5), (0.5, 1.5), (1.5, 3), (3, 99)):
         q = big & (cs >= lo) & (cs < hi)
         if q.sum() > 5: print(f"      other chain waves on the SIMD in [{lo}, {hi}): {q.sum():5d} waves, median duration {np.median(dur[q]):7.2f} ms")
+    for lo, hi in ((0, 3), (3, 6), (6, 9), (9, 12), (12, 16), (16, 99)):
+        q = big & (cc >= lo) & (cc < hi)
+        if q.sum() > 5: print(f"      other chain waves on the CU   in [{lo}, {hi}): {q.sum():5d} waves, median duration {np.median(dur[q]):7.2f} ms")
+    # where: per XCC, and by workgroup index (the launch's dispatch order)
+    if m.sum() >= 512 and np.median(d) > 5:
+        print("      by XCC: " + "  ".join(f"{x}: {np.median(dur[m & (xcc == x)]):5.1f}" for x in np.unique(xcc[m])))
+        blk = rec["blk"][m]; nb = int(blk.max()) + 1
+        qs = [(i * nb // 4, (i + 1) * nb // 4) for i in range(4)]
+        print("      by workgroup index quarter: " + "  ".join(f"[{a},{b}): {np.median(d[(blk >= a) & (blk < b)]):5.1f}" for a, b in qs))
+        percu = {}
+        for c_, dd in zip(cuid[m], d): percu.setdefault(int(c_), []).append(dd)
+        meds = np.array([np.median(v) for v in percu.values() if len(v) >= 3])
+        if len(meds) > 8: print(f"      per-CU median duration over {len(meds)} CUs: p10 {np.percentile(meds,10):5.1f} median {np.median(meds):5.1f} p90 {np.percentile(meds,90):5.1f}")

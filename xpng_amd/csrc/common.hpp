@@ -47,21 +47,23 @@ inline hipError_t chain_stream_create(hipStream_t *s) {
 
 // Wave probe for placement studies (tools/wave_probe.py; probe builds only): when a buffer is registered (xpnghip_debug_probe),
 // wave 0 of every workgroup of the serial-chain kernels records where it ran (HW_ID: SE / CU / SIMD / wave slot; XCC_ID) and
-// when (constant 100 MHz clock).
+// when (constant 100 MHz clock); the upper 28 bits of `xcc` carry the wave's shader-clock cycles / 16 (s_memtime), i.e. the clock it ran at.
 struct WaveProbe { uint32_t kernel, block, hwid, xcc; uint64_t t0, t1; };
 #ifdef XPNG_PROBES
 __device__ WaveProbe *g_probe_buf = nullptr;
 __device__ uint32_t g_probe_cap = 0, g_probe_n = 0;
 #define XPNG_PROBE_BEGIN()                                                                        \
     WaveProbe *const probe_buf_ = g_probe_buf;                                                    \
-    uint64_t probe_t0_ = 0;                                                                       \
-    if (probe_buf_) probe_t0_ = __builtin_amdgcn_s_memrealtime();
+    uint64_t probe_t0_ = 0, probe_c0_ = 0;                                                        \
+    if (probe_buf_) { probe_t0_ = __builtin_amdgcn_s_memrealtime(); probe_c0_ = __builtin_readcyclecounter(); }
 #define XPNG_PROBE_END(kid)                                                                       \
     if (probe_buf_ && threadIdx.x == 0) {                                                         \
         const uint32_t pi_ = atomicAdd(&g_probe_n, 1u);                                           \
         if (pi_ < g_probe_cap)                                                                    \
             probe_buf_[pi_] = WaveProbe{(uint32_t)(kid), blockIdx.x, (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4),     \
-                                        (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20), probe_t0_, __builtin_amdgcn_s_memrealtime()}; \
+                                        ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) |                          \
+                                            ((uint32_t)((__builtin_readcyclecounter() - probe_c0_) >> 4) << 4),                   \
+                                        probe_t0_, __builtin_amdgcn_s_memrealtime()};                                             \
     }
 #else
 #define XPNG_PROBE_BEGIN()

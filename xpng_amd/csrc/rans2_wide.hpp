@@ -176,6 +176,10 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
 #pragma unroll
         for (int u = 0; u < 8; u++) sy[u] = ((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u;
         // (lanes without a stream read their placeholder tile's table: no branch around the loads)
+        // [r4] tried: the entries of the stream's two most frequent symbols in registers and only the other lanes gathering (behind
+        // s_cbranch_execz): bit-exact, 95 % of the gathers gone - and the compiler turns the conditional loads into temporaries that
+        // it copies behind an s_waitcnt vmcnt(0) right after issuing them: 22.3 instead of 19.3 ms alone, and the chain saturates at
+        // the same ~4.5 launches in flight (profiles/r04_experiments.txt): the gathers (98 % L1 hits) are not what it waits for.
 #pragma unroll
         for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; En[u] = EncSym{v.x, v.y, v.z, v.w}; }
     };
