@@ -508,8 +508,9 @@ def main():
         # memory and a down-clocked part, and its bandwidth-bound roofline pair reads 0.31-0.36 instead of the 0.55 of a clean run
         env.torch.cuda.empty_cache()
         for name, lvl in (("rgb_l1", 1), ("rgb_l2", 2)):
-            # (level 2 holds 27 B/px of workspace against level 1's 12: three quarters of the rasters per launch keep it at ~213 GB)
-            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 128) if lvl == 1 else max(1, min(B, 128) * 3 // 4)), "--pipeline", str(min(P, 8)),
+            # (level 2 holds 27 B/px of workspace against level 1's 12: 9/16 of the rasters per launch - 36 of 64 - keep it under 160 GB;
+            #  profiles/r04_experiments.txt: 48 x 8 reads 18.6-19.0 Gpx/s at 210 GB, 36 x 8 17.4 at 158 GB, 24 x 8 17.2 at 106 GB)
+            cmd = [sys.executable, os.path.abspath(__file__), "--rgb", "--level", str(lvl), "--batch", str(min(B, 128) if lvl == 1 else max(1, min(B, 128) * 9 // 16)), "--pipeline", str(min(P, 8)),
                    "--steps", str(max(6, args.steps // 3)), "--warmup", "2", "--roofline-reps", str(max(10, args.roofline_reps // 2)), "--no-legs", "--no-config4"]
             if args.no_cpu:
                 cmd.append("--no-cpu")

@@ -53,8 +53,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             with torch.cuda.stream(sl["stream"]):
                 torch.cuda._sleep(int(i * stagger_ms * 2.4e6))
     steps = int(os.environ.get("KNOCKOUT_STEPS", "20"))
+    # KNOCKOUT_NOISE=n: n one-element kernels on a stream of their own behind every step's launches (do kernel boundaries - their cache
+    # write-backs and invalidations - slow the kernels in flight?)
+    noise = int(os.environ.get("KNOCKOUT_NOISE", "0"))
+    nstream, nbuf = torch.cuda.Stream(), torch.zeros(64, dtype=torch.int32, device="cuda")
     t0 = time.perf_counter()
-    for k in range(steps): step(k)
+    for k in range(steps):
+        step(k)
+        if noise:
+            with torch.cuda.stream(nstream):
+                for _ in range(noise): nbuf.add_(1)
     torch.cuda.synchronize()
     print(f"{(time.perf_counter() - t0) / steps * 1e3:.3f}")
     sys.exit(0)
