@@ -479,8 +479,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     }
     if (alpha_side) {
         HIPCHK(hipEventRecord(c->ev_enc_fork, s));
-        HIPCHK(hipStreamWaitEvent(c->enc_side, c->ev_enc_fork, 0));
-        hipStream_t as = c->enc_side;
+        hipStream_t as = probe_env("XPNG_ONE_STREAM") ? s : c->enc_side;  // (probe builds: every kernel of the context on the caller's stream)
+        HIPCHK(hipStreamWaitEvent(as, c->ev_enc_fork, 0));
         if (jb) {
             HIPCHK(hipStreamWaitEvent(c->enc_side2, c->ev_enc_fork, 0));
             if (!dbg_skip("chain_a")) k_rans2_encode<<<jb, 64, 0, c->enc_side2>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, nullptr);
@@ -622,6 +622,7 @@ extern "C" int xpnghip_decode_device_batch(xpnghip_ctx *c, int mode, const void 
         if (!c->enc_side) HIPCHK(chain_stream_create(&c->enc_side));
         c->dec.side = c->enc_side; c->dec.side_borrowed = true;
     }
+    if (probe_env("XPNG_ONE_STREAM")) { c->dec.side = s; c->dec.side_borrowed = true; }
     XPNG_REQUIRE(c->d_dec_in_ptrs, c->d_dec_out_ptrs, c->d_blob_len, c->d_status, c->d_tiles, c->dec.arena);
     if (mode == 2) {
         if (ensure_m2(c)) return 1;
