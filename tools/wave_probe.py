@@ -57,8 +57,10 @@ cuid = ((xcc.astype(np.int64) * 8 + se) * 2 + sh) * 16 + cu
 simdid = cuid * 4 + simd
 print("distinct CUs seen", len(np.unique(cuid)), "distinct SIMDs", len(np.unique(simdid)), "xcc values", np.unique(xcc), "se", np.unique(se), "sh", np.unique(sh), "cu", np.unique(cu))
 dur = (rec["t1"] - rec["t0"]).astype(np.float64) / 100e3  # ms
-cyc = (rec["xcc"] >> 4).astype(np.float64) * 16.0      # shader-clock cycles of the wave (s_memtime)
-long_ = dur > 5
+has_iss = (rec["xcc"] & 16) != 0
+issf = np.where(has_iss, (rec["xcc"] >> 16).astype(np.float64) / 65536.0, 0.0)   # fraction of its life in the boundary's landing / stores / request issue
+cyc = np.where(has_iss, 0.0, (rec["xcc"] >> 5).astype(np.float64) * 16.0)        # shader-clock cycles of the wave (s_memtime)
+long_ = (dur > 5) & ~has_iss
 if long_.any():
     mhz = cyc[long_] / (dur[long_] * 1e3)
     print(f"shader clock over the waves longer than 5 ms: p10 {np.percentile(mhz,10):.0f} median {np.median(mhz):.0f} p90 {np.percentile(mhz,90):.0f} MHz")
@@ -84,7 +86,7 @@ cs, cc = coresid(simdid), coresid(cuid)
 inst = np.zeros(len(rec), dtype=np.int64)
 seen = {}
 for i in order:
-    key = (int(rec["k"][i]), int(rec["blk"][i]))
+    key = (int(rec["k"][i]), int(rec["blk"][i]) & 0xFFFF)
     inst[i] = seen.get(key, 0); seen[key] = inst[i] + 1
 for k in sorted(names):
     m = rec["k"] == k
@@ -101,6 +103,13 @@ for k in sorted(names):
     if delays:
         dl = np.concatenate(delays)
         print(f"{names[k]:18s} kernel span first start -> last end: median {np.median(spans):6.2f} ms; longest wave of a launch: median {np.median(longest):6.2f} ms; wave start delay after the launch's first wave: median {np.median(dl):6.2f}, p90 {np.percentile(dl,90):6.2f}, max {dl.max():6.2f} ms")
+    wf = (rec["blk"][m] >> 16).astype(np.float64) / 65536.0
+    if wf.max() > 0:
+        lng = d >= np.median(d)
+        print(f"{names[k]:18s} time standing at the block boundary's wait (long waves): median {np.median(wf[lng]) * 100:4.1f} %, p90 {np.percentile(wf[lng], 90) * 100:4.1f} % of the wave's life = {np.median(wf[lng] * d[lng]):5.2f} ms median")
+    if has_iss[m].any():
+        lng = d >= np.median(d); f = issf[m]
+        print(f"{names[k]:18s} time in the rest of the boundary (landing, stores, issuing the next requests; long waves): median {np.median(f[lng]) * 100:4.1f} %, p90 {np.percentile(f[lng], 90) * 100:4.1f} % = {np.median(f[lng] * d[lng]):5.2f} ms median")
     print(f"{names[k]:18s} waves {m.sum():6d}  duration ms: p10 {np.percentile(d,10):7.2f} median {np.median(d):7.2f} p90 {np.percentile(d,90):7.2f} | mean other chain waves on its SIMD {cs[m].mean():5.2f}, on its CU {cc[m].mean():5.2f}")
     # does co-residency explain the duration?  long waves only (the kernel's size class): top half by duration
     big = m & (dur >= np.median(d))
@@ -113,7 +122,7 @@ for k in sorted(names):
     # where: per XCC, and by workgroup index (the launch's dispatch order)
     if m.sum() >= 512 and np.median(d) > 5:
         print("      by XCC: " + "  ".join(f"{x}: {np.median(dur[m & (xcc == x)]):5.1f}" for x in np.unique(xcc[m])))
-        blk = rec["blk"][m]; nb = int(blk.max()) + 1
+        blk = rec["blk"][m] & 0xFFFF; nb = int(blk.max()) + 1
         qs = [(i * nb // 4, (i + 1) * nb // 4) for i in range(4)]
         print("      by workgroup index quarter: " + "  ".join(f"[{a},{b}): {np.median(d[(blk >= a) & (blk < b)]):5.1f}" for a, b in qs))
         percu = {}

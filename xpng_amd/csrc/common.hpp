@@ -47,26 +47,45 @@ inline hipError_t chain_stream_create(hipStream_t *s) {
 
 // Wave probe for placement studies (tools/wave_probe.py; probe builds only): when a buffer is registered (xpnghip_debug_probe),
 // wave 0 of every workgroup of the serial-chain kernels records where it ran (HW_ID: SE / CU / SIMD / wave slot; XCC_ID) and
-// when (constant 100 MHz clock); the upper 28 bits of `xcc` carry the wave's shader-clock cycles / 16 (s_memtime), i.e. the clock it ran at.
+// when (constant 100 MHz clock); bit 4 of `xcc` clear: its bits 5.. carry the wave's shader-clock cycles / 16 (s_memtime), i.e. the clock it ran at; bit 4 set: its upper 16 bits the fraction (x 65536) of its life between XPNG_PROBE_ISSUE_BEGIN and _END; the upper 16 bits of `block` the fraction (x 65536) of its life it stood in XPNG_PROBE_WAIT.
 struct WaveProbe { uint32_t kernel, block, hwid, xcc; uint64_t t0, t1; };
 #ifdef XPNG_PROBES
 __device__ WaveProbe *g_probe_buf = nullptr;
 __device__ uint32_t g_probe_cap = 0, g_probe_n = 0;
 #define XPNG_PROBE_BEGIN()                                                                        \
     WaveProbe *const probe_buf_ = g_probe_buf;                                                    \
-    uint64_t probe_t0_ = 0, probe_c0_ = 0;                                                        \
+    uint64_t probe_t0_ = 0, probe_c0_ = 0, probe_wait_ = 0, probe_iss_ = 0;                       \
+    [[maybe_unused]] uint64_t probe_ia_ = 0;                                                      \
     if (probe_buf_) { probe_t0_ = __builtin_amdgcn_s_memrealtime(); probe_c0_ = __builtin_readcyclecounter(); }
+// at a block boundary of a chain kernel, where the code is about to use what the previous boundary requested (the youngest loads in
+// flight, so the wait it runs into is vmcnt(0) anyway): how long does the wavefront stand there?  (100 MHz ticks, summed)
+#define XPNG_PROBE_WAIT()                                                                         \
+    if (probe_buf_) {                                                                             \
+        const uint64_t pwa_ = __builtin_amdgcn_s_memrealtime();                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        probe_wait_ += __builtin_amdgcn_s_memrealtime() - pwa_;                                   \
+    }
+// ... and how long does the rest of the boundary take - landing the words, the stores, ISSUING the next requests (a vector memory
+// instruction that finds the compute unit's address path full stalls the wavefront at issue, whatever its prefetch distance)?
+#define XPNG_PROBE_ISSUE_BEGIN() if (probe_buf_) { asm volatile("" ::: "memory"); probe_ia_ = __builtin_amdgcn_s_memrealtime(); }
+#define XPNG_PROBE_ISSUE_END() if (probe_buf_) { asm volatile("" ::: "memory"); probe_iss_ += __builtin_amdgcn_s_memrealtime() - probe_ia_; }
 #define XPNG_PROBE_END(kid)                                                                       \
     if (probe_buf_ && threadIdx.x == 0) {                                                         \
         const uint32_t pi_ = atomicAdd(&g_probe_n, 1u);                                           \
         if (pi_ < g_probe_cap)                                                                    \
-            probe_buf_[pi_] = WaveProbe{(uint32_t)(kid), blockIdx.x, (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4),     \
+            probe_buf_[pi_] = WaveProbe{(uint32_t)(kid),                                                                           \
+                                        (blockIdx.x & 0xFFFFu) | ((uint32_t)((probe_wait_ << 16) / ((__builtin_amdgcn_s_memrealtime() - probe_t0_) | 1)) << 16), \
+                                        (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4),                                       \
                                         ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) |                          \
-                                            ((uint32_t)((__builtin_readcyclecounter() - probe_c0_) >> 4) << 4),                   \
+                                            (probe_iss_ ? ((uint32_t)((probe_iss_ << 16) / ((__builtin_amdgcn_s_memrealtime() - probe_t0_) | 1)) << 16) | 0x10u \
+                                                        : ((uint32_t)((__builtin_readcyclecounter() - probe_c0_) >> 4) << 5)),   \
                                         probe_t0_, __builtin_amdgcn_s_memrealtime()};                                             \
     }
 #else
 #define XPNG_PROBE_BEGIN()
+#define XPNG_PROBE_WAIT()
+#define XPNG_PROBE_ISSUE_BEGIN()
+#define XPNG_PROBE_ISSUE_END()
 #define XPNG_PROBE_END(kid)
 #endif
 

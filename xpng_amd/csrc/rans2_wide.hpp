@@ -140,18 +140,19 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     uint32_t *wb = wbuf + (k < TPW ? k : 0) * WB_STRIDE;
     const uint32_t dumpw = wb_dump(k < TPW ? k : 0, par);
     // symbols of block b (pair symbols 16b .. 16b+15) = bytes [16b + SH, 16b + SH + 16) of `in`
-    uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0;  // in flight: the block after the current one
+    u32x4_enc fq = u32x4_enc{0, 0, 0, 0};  // in flight: the block after the current one (ONE 128-bit value: four 32-bit loop-carried values
+    uint32_t f4 = 0;                       // get registers of their own and are copied out of the load's tuple behind a wait for it)
     // (unconditional, on a clamped block index: a branch around the loads makes the compiler keep the loaded values in
     //  temporaries and copy them into the loop-carried registers right away, and that copy waits for the load it follows)
     const uint32_t last_blk = mysteps ? (mysteps - 1) >> 3 : 0;
     auto request = [&](uint32_t b) __attribute__((always_inline)) {
         const uint8_t *a = in + 16ull * (b < last_blk ? b : last_blk);
-        const uint4 v = *reinterpret_cast<const uint4 *>(a);
-        f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
+        fq = *reinterpret_cast<const u32x4_enc *>(a);
         if (SH) f4 = *reinterpret_cast<const uint32_t *>(a + 16);
     };
     uint32_t sy0 = 0, sy1 = 0;  // this lane's 8 symbols of the current block, one per byte
     auto land = [&]() __attribute__((always_inline)) {
+        const uint32_t f0 = fq.x, f1 = fq.y, f2 = fq.z, f3 = fq.w;
         uint32_t d0 = f0, d1 = f1, d2 = f2, d3 = f3;
         if (SH) {
             d0 = __builtin_amdgcn_alignbyte(f1, f0, SH); d1 = __builtin_amdgcn_alignbyte(f2, f1, SH);
@@ -170,28 +171,35 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     constexpr int thr_shift = 31 - PB;
     uint64_t s = RANS_L;
     uint32_t cnt = 0;
-    EncSym E[8], En[8];
-    auto entries = [&]() __attribute__((always_inline)) {  // entries of the block whose symbols are in sy0/sy1 -> En
+    // BIG: two sets of eight entries, X and Y, used ALTERNATELY: a block steps on one set and refills that same set at its boundary (for
+    // the block after next, whose symbols have just landed) while the next block steps on the other.  [r4] Rounds 3-4 shipped "E = the
+    // current block's entries, En = the next block's, E = En at the boundary": the compiler treats that copy as a loop-carried value and
+    // sinks it to the loop's back edge, behind the gathers - En's old and new values are then alive together, the gathers land in
+    // temporaries, and the back edge copies those into En behind an s_waitcnt vmcnt(0): every block waited for the loads it had just
+    // issued (a wavefront spent 12 % of its life in this boundary alone, 26 % at 8 pipeline slots: tools/wave_probe.py), and 32 register
+    // moves per block came on top.  With two sets and the loop unrolled twice nothing is copied and a gather has a whole block to land.
+    EncSym X[8], Y[8];
+    auto entries = [&](EncSym (&A)[8]) __attribute__((always_inline)) {  // entries of the block whose symbols are in sy0/sy1 -> A
         uint32_t sy[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) sy[u] = ((u < 4 ? sy0 : sy1) >> (8 * (u & 3))) & 255u;
         // (lanes without a stream read their placeholder tile's table: no branch around the loads)
         // [r4] tried: the entries of the stream's two most frequent symbols in registers and only the other lanes gathering (behind
-        // s_cbranch_execz): bit-exact, 95 % of the gathers gone - and the compiler turns the conditional loads into temporaries that
-        // it copies behind an s_waitcnt vmcnt(0) right after issuing them: 22.3 instead of 19.3 ms alone, and the chain saturates at
-        // the same ~4.5 launches in flight (profiles/r04_experiments.txt): the gathers (98 % L1 hits) are not what it waits for.
+        // s_cbranch_execz; bit-exact, 95 % of the gathers gone).  A conditional load makes the number of loads in flight unknown to the
+        // compiler, so every wait behind one becomes vmcnt(0): the block that follows waits for the gathers just issued.  (In the
+        // E / En form of rounds 3-4: 22.3 instead of 19.3 ms alone; as inline assembly on the destination registers the compiler copies
+        // those registers, unlanded, at the back edge.)  profiles/r04_experiments.txt.
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; En[u] = EncSym{v.x, v.y, v.z, v.w}; }
+        for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; A[u] = EncSym{v.x, v.y, v.z, v.w}; }
     };
     request(0); land(); request(1);
     EncSym e = EncSym{0, 0, 0, 0};
     if (BIG) {
-        entries();                       // En = entries of block 0
-#pragma unroll
-        for (int u = 0; u < 8; u++) E[u] = En[u];
-        land(); request(2); entries();   // symbols of block 1 land, block 2 is requested, En = entries of block 1 (in flight)
+        entries(X);                       // X = entries of block 0
+        land(); request(2); entries(Y);   // symbols of block 1 land, block 2 is requested, Y = entries of block 1 (in flight)
     } else e = tab[sy0 & 255u];
-    for (uint32_t kb = 0; kb < T; kb += 8) {
+    // one block: eight steps on the entries A (BIG), then the boundary
+    auto block = [&](const uint32_t kb, EncSym (&A)[8]) __attribute__((always_inline)) {
         uint32_t cb = 0;  // words the pair has staged in this block
         // eight steps; FULL (compile time): every lane of the wave is inside its stream for the whole block, no per-lane activity test
         auto steps8 = [&](auto fullc) __attribute__((always_inline)) {
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 EncSym en = e;
-                if (BIG) e = E[u];
+                if (BIG) e = A[u];
                 else if (u < 7) en = tab[((u + 1 < 4 ? sy0 : sy1) >> (8 * ((u + 1) & 3))) & 255u];  // entry of the NEXT step, under this step's arithmetic
                 const bool act = FULL || kb + (uint32_t)u < mysteps;
                 const uint32_t freq = e.freq_shift & 0xFFFF, rsh = e.freq_shift >> 16;
@@ -215,7 +223,14 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
                 if (act) {
                     const uint64_t rcp = ((uint64_t)e.rcp_hi << 32) | e.rcp_lo;
                     const uint64_t q = __umul64hi(s, rcp) >> rsh;
-                    s += e.bias + q * (uint64_t)(cmpl_base - freq);
+                    if (BIG) {
+                        // (the bias is added with a carry chain: as a 64-bit add the compiler wants it in a register PAIR (bias, 0), copies
+                        //  it there out of the gathered entry at the loop's back edge - and waits for the gathers it has just issued)
+                        const uint64_t t = s + q * (uint64_t)(cmpl_base - freq);
+                        uint32_t tl = (uint32_t)t, th = (uint32_t)(t >> 32);
+                        asm("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(tl), "+v"(th) : "v"(e.bias) : "vcc");
+                        s = ((uint64_t)th << 32) | tl;
+                    } else s += e.bias + q * (uint64_t)(cmpl_base - freq);
                 }
                 if (!BIG) e = en;
             }
@@ -225,10 +240,8 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         // ---- boundary: the next block's symbols land FIRST (the wait in front of it then covers the load issued a block ago
         // and nothing younger: behind this block's stores it would also wait for their acknowledgement), then the staged
         // words go out (lane `par` stores words 8 par .. 8 par + 7) and the block after next is requested
-        if (BIG) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) E[u] = En[u];  // the next block's entries, requested a block ago
-        }
+        XPNG_PROBE_WAIT()
+        XPNG_PROBE_ISSUE_BEGIN()
         land();
         asm volatile("" : "+v"(sy0), "+v"(sy1) : : "memory");  // (pins the landing in front of the stores)
         if (cb > 8 * par) {
@@ -241,8 +254,18 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         }
         cnt += cb;
         request((kb >> 3) + (BIG ? 3 : 2));
-        if (BIG) entries();
+        if (BIG) entries(A);   // the set this block has just finished with: entries of the block after next
         else e = tab[sy0 & 255u];
+        XPNG_PROBE_ISSUE_END()
+    };
+    if (BIG) {
+        for (uint32_t kb = 0; kb < T; kb += 16) {
+            block(kb, X);
+            if (kb + 8 >= T) break;
+            block(kb + 8, Y);
+        }
+    } else {
+        for (uint32_t kb = 0; kb < T; kb += 8) block(kb, X);
     }
     if (live) { p->st[par] = s; if (par == 0) p->cnt = cnt; }
     XPNG_PROBE_END(BIG ? 2 : 1)

@@ -450,6 +450,8 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
         rw -= (wi0 - wi) & (WD_RING - 1);  // words the pair consumed in this block (at most two per step)
         // ---- block boundary: in-flight words land, symbols out, next words requested
         // (landing first: its wait then covers only what the previous boundary issued, 8 steps ago, not this block's store)
+        XPNG_PROBE_WAIT()
+        XPNG_PROBE_ISSUE_BEGIN()
         {   // (unconditional, like the request below: fhi == 0 when nothing was requested)
             const uint32_t dw[9] = {q0.x, q0.y, q0.z, q0.w, PER > 4 ? q1.x : qx, q1.y, q1.z, q1.w, qx};
 #pragma unroll
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(64) void k_rans2_dec_chain(const DecTile *__restric
                 lof = any ? (uint32_t)want : lof;
             }
         }
+        XPNG_PROBE_ISSUE_END()
     }
     XPNG_PROBE_END(BIG ? 4 : 3)
 }
