@@ -24,6 +24,14 @@ struct WPrep {
     uint64_t st[2];             // final states
 };
 __device__ __forceinline__ uint32_t wtab_off(uint32_t c) { return c < 9 ? 4096 + c * 256 : 0; }
+// [r4] The ALPHA encoder tables of a launch live interleaved, 32 streams (one chain wavefront's) to a group: entry e of the group's
+// stream k at group * WATAB_GROUP_BYTES + e * 512 + k * 16.  A chain wavefront gathers one entry per lane and step; with a table per
+// stream (rounds 3-4: 4 KB each, 6.4 KB apart) that is 64 different L1 lines per instruction whatever the symbols are - 767 M of a
+// step's 4 249 M L1 accesses (profiles/r04_pmc_step_l2.json), and the compute unit's address path, one line per cycle, is what the chain
+// wavefronts of 8 pipeline slots queue for at their block boundaries (tools/wave_probe.py).  Interleaved, the lanes
+// whose symbol is the same - alpha residuals are mostly ONE value - read the same four lines.
+constexpr uint32_t WATAB_GROUP_BYTES = 256u * 32u * 16u;
+__host__ __device__ inline uint64_t watab_bytes(uint64_t streams) { return ((streams + 31) / 32 + 1) * WATAB_GROUP_BYTES; }
 // (The alpha tables, 4 KB each, never enter LDS: the chain gathers the entries of a block from the table in global memory
 //  - L2 - one block ahead.  Rounds 1-3 kept a 1 KB compact form per resident stream in LDS; LDS bytes x residency time summed
 //  over the kernels of a pipelined step is what the step time tracks, and 162 waves x 37 KB x 26 ms was the
@@ -37,7 +45,8 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
                                                    const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                    uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
                                                    uint32_t *__restrict__ blk_sz, WPrep *__restrict__ prep,
-                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF, uint32_t j0) {
+                                                   uint8_t *__restrict__ wtab, uint16_t *__restrict__ wF, uint32_t j0,
+                                                   uint8_t *__restrict__ watab) {
     bw_prio();
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cum[260];
@@ -70,7 +79,13 @@ __global__ __launch_bounds__(64) void k_rans2_prep(const TileDesc *__restrict__ 
     rans_tables(hist, cum, tab, N, n, pb);
     EncSym *gt = reinterpret_cast<EncSym *>(wtab + (uint64_t)tile * WTAB_TILE_BYTES + wtab_off(c));
     uint16_t *gF = wF + ((uint64_t)tile * 10 + c) * 256;
-    for (uint32_t i = lane; i < N; i += 64) { gt[i] = tab[i]; gF[i] = (uint16_t)hist[i]; }
+    if (c == 9) {  // (alpha: the launch's interleaved layout; the stream's place in it is its work-item index, as the chain kernel counts it)
+        const uint32_t jr = blockIdx.x / c_count;
+        gt = reinterpret_cast<EncSym *>(watab + (uint64_t)(jr >> 5) * WATAB_GROUP_BYTES + (jr & 31u) * 16u);
+        for (uint32_t i = lane; i < N; i += 64) { gt[i * 32u] = tab[i]; gF[i] = (uint16_t)hist[i]; }
+    } else {
+        for (uint32_t i = lane; i < N; i += 64) { gt[i] = tab[i]; gF[i] = (uint16_t)hist[i]; }
+    }
     if (lane == 0) *p = WPrep{1, N, distinct, 0, {0, 0}};
 }
 
@@ -93,7 +108,8 @@ template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict__ tiles, TileSel sel, uint32_t total,
                                                      const uint8_t *__restrict__ planes, uint64_t plane_stride,
                                                      uint8_t *__restrict__ scratch, const uint32_t *__restrict__ ctx_n,
-                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab, uint32_t j0) {
+                                                     WPrep *__restrict__ prep, const uint8_t *__restrict__ wtab, uint32_t j0,
+                                                     const uint8_t *__restrict__ watab) {
     constexpr uint32_t TPW = 32;                  // tiles (streams) per wave: every lane carries a state (alpha ran 16 per wave while its tables took 4 KB of LDS each)
     // bytes of one encoder table in LDS: a context stream has the nine symbols nl = 0..8 (the alpha class keeps none there)
     constexpr uint32_t TAB = 144;
@@ -166,7 +182,9 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
     // table in global memory (global address space: a pointer computed from a kernel argument through a struct would be
     // generic, and flat loads also count on lgkmcnt); no table access inside a block, and every load has a whole block to return
     typedef const __attribute__((address_space(1))) u32x4_enc *gent;
-    const gent gfull = (gent)(uintptr_t)(wtab + (uint64_t)tile * WTAB_TILE_BYTES);
+    // (the stream's column of its group's interleaved table: entry e at gfull[e * 32]; lanes without a stream read their own, unwritten
+    //  column - inside the allocation, and their steps are inactive)
+    const gent gfull = (gent)(uintptr_t)(watab + (uint64_t)grp * WATAB_GROUP_BYTES + (k & 31u) * 16u);
     constexpr uint32_t cmpl_base = 1u << PB;
     constexpr int thr_shift = 31 - PB;
     uint64_t s = RANS_L;
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
         // E / En form of rounds 3-4: 22.3 instead of 19.3 ms alone; as inline assembly on the destination registers the compiler copies
         // those registers, unlanded, at the back edge.)  profiles/r04_experiments.txt.
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u]]; A[u] = EncSym{v.x, v.y, v.z, v.w}; }
+        for (int u = 0; u < 8; u++) { const u32x4_enc v = gfull[sy[u] * 32u]; A[u] = EncSym{v.x, v.y, v.z, v.w}; }
     };
     request(0); land(); request(1);
     EncSym e = EncSym{0, 0, 0, 0};

@@ -250,7 +250,7 @@ static int ctx_create_range_impl(xpnghip_ctx **out, int device, uint64_t w, uint
     ALLOC(c->d_dbg, VN * 10 * 8 * 8 * 2);  // phase stamps of the chain kernels (XPNG_STAMPS)
 #endif
     ALLOC(c->d_wprep, VN * 10 * sizeof(WPrep));
-    ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096);
+    ALLOC(c->d_wtab, VN * WTAB_TILE_BYTES + 4096 + watab_bytes(VN));  // per-tile tables, then the launch's interleaved alpha tables (rans2_wide.hpp)
     ALLOC(c->d_wF, VN * 10 * 512);
     ALLOC(c->d_blob_len, (uint64_t)batch * 8);
     ALLOC(c->d_status, 64);
@@ -449,6 +449,7 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
     XPNG_REQUIRE(c->d_planes, c->d_in_ptrs, c->d_out_ptrs, c->d_tiles, c->d_scratch, c->d_sums, c->d_ctx_n, c->d_k_n,
                  c->d_blk_sz, c->d_tile_sz, c->d_tile_hdr, c->d_off, c->d_totals, c->d_wprep, c->d_wtab, c->d_wF, c->h_total);
     const uint8_t *planesA = c->d_planes;
+    uint8_t *const watab = c->d_wtab + (((uint64_t)c->tiles.size() * c->B * WTAB_TILE_BYTES + 4096 + 511) & ~511ull);
     const bool alpha_side = !narrow && PXSZ == 4;
     if (alpha_side && !c->enc_side) HIPCHK(chain_stream_create(&c->enc_side));
     if (alpha_side && !c->ev_enc_fork) {
@@ -486,8 +487,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
             if (!dbg_skip("chain_a")) k_rans2_encode<<<jb, 64, 0, c->enc_side2>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, nullptr);
             HIPCHK(hipEventRecord(c->ev_enc_join2, c->enc_side2));
         }
-        if (!dbg_skip("prep_a")) k_rans2_prep<<<total - jb, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, jb);
-        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total - jb + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, jb);
+        if (!dbg_skip("prep_a")) k_rans2_prep<<<total - jb, 64, 0, as>>>(c->d_tiles, sel, 9, 1, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, jb, watab);
+        if (!dbg_skip("chain_a")) k_rans2_chain2<true><<<(total - jb + 31) / 32, 64, chain2_lds_bytes<true>() + probe_pad("XPNG_PAD_CHAIN"), as>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, jb, watab);
         HIPCHK(hipEventRecord(c->ev_enc_join, as));
     }
     // stream lengths (from the histogram of the nl plane the transform took as it wrote it) -> places of the nine context streams -> routing
@@ -498,8 +499,8 @@ static int launch_encode_m1(xpnghip_ctx *c, uint32_t nimg, uint32_t t0, uint32_t
         // one wave per (tile, stream): fewer instructions per step (scalar cursors), best latency while every pair gets its own wave slot
         k_rans2_encode<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, 0, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, nullptr, c->stamps ? c->d_dbg : nullptr);
     } else {                           // every lane a chain: prep -> chain -> finish
-        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, 0);
-        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, 0);
+        if (!dbg_skip("prep_c")) k_rans2_prep<<<total * 9, 64, 0, s>>>(c->d_tiles, sel, 0, 9, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wtab, c->d_wF, 0, watab);
+        if (!dbg_skip("chain_c")) k_rans2_chain2<false><<<((total + 31) / 32) * 9, 64, chain2_lds_bytes<false>() + probe_pad("XPNG_PAD_CHAIN"), s>>>(c->d_tiles, sel, total, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_wprep, c->d_wtab, 0, watab);
         if (alpha_side) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join, 0));
         if (jb) HIPCHK(hipStreamWaitEvent(s, c->ev_enc_join2, 0));
         if (!dbg_skip("finish")) k_rans2_finish<<<total * c->spt, 64, 0, s>>>(c->d_tiles, sel, c->spt, planesA, c->plane_stride, c->d_scratch, c->d_ctx_n, c->d_blk_sz, c->d_wprep, c->d_wF);
