@@ -16,6 +16,15 @@
 namespace xpng {
 
 // slots with at most 9 symbols use the register search (small layout); the rest the LDS tables (big layout)
+// big-alphabet slots of mode 2: WdLayoutA's byte layout with 2^XPNG_W1D_CBITS coarse bytes (r4 experiment: 8 instead of 9 = 772 instead
+// of 1 028 bytes of LDS per resident stream, 64-slot instead of 32-slot buckets for the scan)
+#ifndef XPNG_W1D_CBITS
+#define XPNG_W1D_CBITS 9
+#endif
+struct W1dLayoutA {
+    static constexpr uint32_t CBITS = XPNG_W1D_CBITS, FCN = 256, RING = 64, REGN = 9;
+    static constexpr uint32_t CO_OFF = 2 * (FCN + 2), TAB = CO_OFF + (1u << CBITS);
+};
 __host__ __device__ inline bool w1d_small(uint32_t slot) { return m2_nominal(slot) <= WdLayout<false>::REGN; }
 __device__ __constant__ const uint8_t W1D_SMALL_SLOT[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11};
 __device__ __constant__ const uint8_t W1D_BIG_SLOT[7] = {10, 12, 13, 14, 15, 16, 17};
@@ -86,15 +95,15 @@ __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restri
     // coarse bytes - the byte layout of rans2_wide_dec.hpp's WdLayoutA, but indexed by the SLOT (residual alphabets are not
     // skewed enough for the cold-rank form to pay: measured 108 ms against 76 per 32 images).  1 KB of LDS per resident stream
     // instead of 2 KB: a chain wave holds its 32 tables for its whole life, and LDS is what the pipelined slots run out of first.
-    const uint32_t co_off = small ? WdLayout<false>::CO_OFF : WdLayoutA::CO_OFF;
-    const uint32_t cbits = small ? WdLayout<false>::CBITS : WdLayoutA::CBITS;
+    const uint32_t co_off = small ? WdLayout<false>::CO_OFF : W1dLayoutA::CO_OFF;
+    const uint32_t cbits = small ? WdLayout<false>::CBITS : W1dLayoutA::CBITS;
     uint8_t *gt = dtab + ((uint64_t)j * M2_SLOTS + slot) * WD_TAB_MAX;
     if (small) {
         uint32_t *gfc = reinterpret_cast<uint32_t *>(gt);
         for (uint32_t i = lane; i <= WdLayout<false>::FCN; i += 64) gfc[i] = i < Nnom ? fc[i] : 0xFFFFu;
     } else {
         uint16_t *gcu = reinterpret_cast<uint16_t *>(gt);
-        for (uint32_t i = lane; i <= WdLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < Nnom ? fc[i] >> 16 : (i == Nnom ? 1u << pb : 0x8000u));
+        for (uint32_t i = lane; i <= W1dLayoutA::FCN + 1; i += 64) gcu[i] = (uint16_t)(i < Nnom ? fc[i] >> 16 : (i == Nnom ? 1u << pb : 0x8000u));
     }
     {   // coarse slot -> symbol
         const uint32_t sh = pb > cbits ? pb - cbits : 0, entries = 1u << (pb - sh);
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(64) void k_rans1_dec_prep(const M2DecTile *__restri
 }
 
 template <bool BIG> struct Dec1ChainLds {  // dynamic LDS layout of one launch (common.hpp: why dynamic)
-    typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
+    typedef typename std::conditional<BIG, W1dLayoutA, WdLayout<false>>::type L;
     static constexpr uint32_t STREAMS = 32, TSTRIDE = L::TAB + 4, RSTRIDE = 4 * L::RING + 4;
     static constexpr uint32_t OFF_RING = (STREAMS * TSTRIDE + 15u) & ~15u, OFF_OBUF = (OFF_RING + STREAMS * RSTRIDE + 31u) & ~31u;
     static constexpr size_t BYTES = OFF_OBUF + STREAMS * OB_STRIDE + 12;
@@ -133,7 +142,7 @@ template <bool BIG> struct Dec1ChainLds {  // dynamic LDS layout of one launch (
 template <bool BIG>
 __global__ __launch_bounds__(64) void k_rans1_dec_chain(const M2DecTile *__restrict__ info, uint32_t total, const WDec *__restrict__ wdec,
                                                         const uint8_t *__restrict__ dtab, uint8_t *__restrict__ scratch2) {
-    typedef typename std::conditional<BIG, WdLayoutA, WdLayout<false>>::type L;
+    typedef typename std::conditional<BIG, W1dLayoutA, WdLayout<false>>::type L;
     constexpr uint32_t CBITS = L::CBITS, TAB = L::TAB, RING = L::RING, KIND = BIG ? 2 : 1, STREAMS = 32, NSLOT = BIG ? 7 : 11;
     constexpr uint32_t TSTRIDE = TAB + 4;
     constexpr uint32_t PER = RING / 8;            // words one lane requests per boundary
