@@ -244,8 +244,11 @@ __global__ __launch_bounds__(64) void k_rans2_chain2(const TileDesc *__restrict_
                     if (BIG) {
                         // (the bias is added with a carry chain: as a 64-bit add the compiler wants it in a register PAIR (bias, 0), copies
                         //  it there out of the gathered entry at the loop's back edge - and waits for the gathers it has just issued)
-                        const uint64_t t = s + q * (uint64_t)(cmpl_base - freq);
-                        uint32_t tl = (uint32_t)t, th = (uint32_t)(t >> 32);
+                        // (q = s / freq < 2^48 behind the spill test and cmpl <= 2^15: the high half of q x cmpl is one 24-bit multiply-add
+                        //  into the high word; as a 64 x 32 multiply the compiler builds a (word, 0) register pair for a second 64-bit one)
+                        const uint32_t cm = cmpl_base - freq;
+                        const uint64_t t = s + (uint64_t)(uint32_t)q * cm;
+                        uint32_t tl = (uint32_t)t, th = (uint32_t)(t >> 32) + __umul24((uint32_t)(q >> 32), cm);
                         asm("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(tl), "+v"(th) : "v"(e.bias) : "vcc");
                         s = ((uint64_t)th << 32) | tl;
                     } else s += e.bias + q * (uint64_t)(cmpl_base - freq);
