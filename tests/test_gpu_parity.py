@@ -405,6 +405,47 @@ def test_large_batch_takes_the_wide_path_and_matches(gpu, po, monkeypatch, alpha
     ctx.close()
 
 
+def test_wide_alpha_chains_on_adversarial_alpha_planes(gpu, po):
+    """The wide alpha ENCODE chain (rans2_wide.hpp) gathers its table entries from tables interleaved across the 32 streams of a
+    wavefront, two entry sets used alternately [r4]: alpha planes that stress it - constant (one symbol: no chain at all), two values,
+    all 256 values, a single odd pixel, ramps - mixed inside ONE launch, so that streams of every kind share wavefronts; 37 rasters of
+    6 tiles (222 alpha streams: six full groups of 32 and a ragged seventh).  Bytes against the oracle, then the decode round trip."""
+    import torch
+    from xpng_amd.api import walk_tile_offsets
+    from xpng_amd.synth import synth_raster
+    W, H, B = 1210, 700, 37
+    rng = np.random.default_rng(11)
+    base = []
+    for kind in range(6):
+        r = synth_raster("photo" if kind % 2 else "noise", W, H, True, seed=20 + kind).copy()
+        if kind == 0: r[..., 3] = 200                                        # one symbol everywhere
+        elif kind == 1: r[..., 3] = np.where(rng.random((H, W)) < 0.02, 3, 250)  # two values, one rare
+        elif kind == 2: r[..., 3] = rng.integers(1, 256, (H, W))              # every value, no structure
+        elif kind == 3: r[..., 3] = 255; r[H // 2, W // 3, 3] = 17            # opaque but for one pixel
+        elif kind == 4: r[..., 3] = (np.arange(W)[None, :] // 5 + np.arange(H)[:, None] // 3) % 255 + 1   # ramps: a few small deltas
+        else: r[..., 3] = np.where((np.arange(W)[None, :] // 64 + np.arange(H)[:, None] // 64) % 2 == 0, 1, 255)  # blocks: rare big jumps
+        base.append(np.ascontiguousarray(r))
+    ctx = gpu.Context(W, H, 4, batch=B)
+    assert ctx.n_tiles * 10 * B > 2048 and (ctx.n_tiles * B) % 32 != 0
+    d_r = [torch.from_numpy(base[i % 6]).cuda() for i in range(B)]
+    d_b = [torch.empty(ctx.blob_bound() + 64, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    want = [po.encode_tiles(1, r) for r in base]
+    for rep in range(2):  # (twice: the second launch finds the first one's tables in the interleaved region)
+        lens = ctx.encode_device_batch(1, [t.data_ptr() for t in d_r], [t.data_ptr() for t in d_b])
+        offs = []
+        for i in range(B):
+            blob = d_b[i][:lens[i]].cpu().numpy().tobytes()
+            assert blob == want[i % 6], (rep, i)
+            offs.append(walk_tile_offsets(blob, ctx.n_tiles)[0])
+    d_o = [torch.full((W * H * 4 + 64,), 0x5A, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    ctx.decode_device_batch(1, [t.data_ptr() for t in d_b], lens, offs, [t.data_ptr() for t in d_o])
+    torch.cuda.synchronize()
+    assert ctx.decode_status() == 0
+    for i in range(B):
+        assert np.array_equal(d_o[i][: W * H * 4].cpu().numpy().reshape(H, W, 4), base[i % 6]), i
+    ctx.close()
+
+
 def test_normalize_rgba_on_device_matches_oracle(gpu, po):
     """normalize_RGBA (libxpng.c:688-721) as device kernels: hidden colour -> zeroed, opaque -> RGB, translucent -> unchanged;
     odd pixel counts exercise the tails of the 4-pixel-per-thread kernels."""
